@@ -1,0 +1,437 @@
+"""CPU restatement (pure PyTorch, fp32) of the SRCGAN training hot path.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Every network is a
+*function of a state_dict* (same key names / shapes as the reference modules)
+so the product modules and this oracle can be evaluated on literally the same
+weights.  Each function cites the reference lines it restates.
+
+Parity: pinned against vectors produced by the imported reference
+(tests/golden/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Dict[str, Tensor]
+
+LRELU_SLOPE = 0.2      # rddb.py:60,96 ; model/model.py:612-631
+RES_SCALE = 0.2        # "lemda" default, rddb.py:62,78
+BN_EPS = 1e-5          # nn.BatchNorm2d default used at model/model.py:598
+BN_MOMENTUM = 0.1
+
+__all__ = [
+    "LRELU_SLOPE", "RES_SCALE", "rdb_forward", "rrdb_forward", "rddbnet_forward",
+    "rddbnet_state", "rddbnet_keys", "nlayer_d_forward", "nlayer_d_state",
+    "nlayer_d_keys", "l1_loss", "mse_loss", "psnr", "gan_loss", "rgb_to_gray",
+    "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
+    "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
+    "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
+]
+
+
+# ---------------------------------------------------------------------------
+# Generator: RDDBNet  (reference src/model/rddb.py:48-114)
+# ---------------------------------------------------------------------------
+def _lrelu(t: Tensor) -> Tensor:
+    return F.leaky_relu(t, LRELU_SLOPE)
+
+
+def rdb_forward(sd: State, pre: str, x: Tensor) -> Tensor:
+    """ResidualDenseBlock_5.forward, rddb.py:62-68: five 3x3 convs over a growing
+    concatenation, LeakyReLU(0.2) after the first four, out = 0.2*x5 + x."""
+    feats = [x]
+    for k in range(1, 6):
+        inp = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
+        y = F.conv2d(inp, sd[f"{pre}conv{k}.weight"], sd[f"{pre}conv{k}.bias"], 1, 1)
+        if k < 5:
+            feats.append(_lrelu(y))
+    return y * RES_SCALE + x
+
+
+def rrdb_forward(sd: State, pre: str, x: Tensor) -> Tensor:
+    """RRDB.forward, rddb.py:78-82: three dense blocks, out = 0.2*out + x."""
+    out = x
+    for j in (1, 2, 3):
+        out = rdb_forward(sd, f"{pre}RDB{j}.", out)
+    return out * RES_SCALE + x
+
+
+def rddbnet_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
+    """RDDBNet.forward, rddb.py:107-114.  Number of RRDBs is read from the keys.
+    Up-sampler: ConvTranspose2d(k=2,s=2,p=0,no bias)+LeakyReLU per x2 stage
+    (rddb.py:9-38,93-97)."""
+    nb = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("RRDB_trunk."))
+    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    t = fea
+    for i in range(nb):
+        t = rrdb_forward(sd, f"RRDB_trunk.{i}.", t)
+    t = F.conv2d(t, sd["trunk_conv.weight"], sd["trunk_conv.bias"], 1, 1)
+    fea = fea + t
+    if upscale_factor != 1:
+        for s in range(int(math.log2(upscale_factor))):
+            fea = _lrelu(F.conv_transpose2d(fea, sd[f"upscale_layers.{2 * s}.weight"], None, 2, 0))
+    return F.conv2d(fea, sd["conv_last.weight"], None, 1, 1)
+
+
+def rddbnet_keys(nb: int, up: int) -> List[str]:
+    """state_dict key order of the reference RDDBNet."""
+    keys = ["conv_first.weight", "conv_first.bias"]
+    for i in range(nb):
+        for j in (1, 2, 3):
+            for k in range(1, 6):
+                keys += [f"RRDB_trunk.{i}.RDB{j}.conv{k}.weight", f"RRDB_trunk.{i}.RDB{j}.conv{k}.bias"]
+    keys += ["trunk_conv.weight", "trunk_conv.bias"]
+    for s in range(int(math.log2(up)) if up > 1 else 0):
+        keys.append(f"upscale_layers.{2 * s}.weight")
+    keys.append("conv_last.weight")
+    return keys
+
+
+def _kaiming_normal_fan_out(shape, gen) -> Tensor:
+    # nn.init.kaiming_normal_(mode='fan_out', nonlinearity='relu'), rddb.py:100-102
+    fan_out = shape[0] * shape[2] * shape[3]
+    return torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_out)
+
+
+def _default_uniform(shape, fan_in, gen) -> Tensor:
+    # torch default Conv/ConvTranspose reset_parameters: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    bound = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def rddbnet_state(in_ch: int, ou_ch: int, up: int, nf: int = 64, nb: int = 3, gc: int = 32,
+                  seed: int = 0) -> State:
+    """Random state with the reference's *distributions* (not its RNG stream):
+    Conv2d weights kaiming-normal(fan_out, relu), biases and ConvTranspose2d
+    weights torch-default uniform (rddb.py:100-105; SURVEY section 7 hard parts)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: State = {}
+
+    def conv(name, co, ci, k, bias=True):
+        sd[name + ".weight"] = _kaiming_normal_fan_out((co, ci, k, k), g)
+        if bias:
+            sd[name + ".bias"] = _default_uniform((co,), ci * k * k, g)
+
+    conv("conv_first", nf, in_ch, 3)
+    for i in range(nb):
+        for j in (1, 2, 3):
+            p = f"RRDB_trunk.{i}.RDB{j}."
+            for k in range(1, 5):
+                conv(p + f"conv{k}", gc, nf + (k - 1) * gc, 3)
+            conv(p + "conv5", nf, nf + 4 * gc, 3)
+    conv("trunk_conv", nf, nf, 3)
+    for s in range(int(math.log2(up)) if up > 1 else 0):
+        # ConvTranspose2d weight [in, out, 2, 2]; torch fan_in for it = out*kh*kw
+        sd[f"upscale_layers.{2 * s}.weight"] = _default_uniform((nf, nf, 2, 2), nf * 4, g)
+    conv("conv_last", ou_ch, nf, 3, bias=False)
+    return {k: sd[k] for k in rddbnet_keys(nb, up)}
+
+
+# ---------------------------------------------------------------------------
+# Discriminator: NLayerDiscriminator (reference src/model/model.py:595-639)
+# ---------------------------------------------------------------------------
+def _d_plan(n_layers: int) -> List[Tuple[int, int, bool, bool]]:
+    """(sequential index of conv, stride, has_bias, followed_by_bn) per conv,
+    model/model.py:612-634."""
+    plan = [(0, 2, True, False)]
+    idx = 2
+    for _ in range(1, n_layers):
+        plan.append((idx, 2, False, True))
+        idx += 3
+    plan.append((idx, 1, False, True))
+    idx += 3
+    plan.append((idx, 1, True, False))
+    return plan
+
+
+def nlayer_d_keys(n_layers: int) -> List[str]:
+    keys: List[str] = []
+    for (i, _s, has_bias, bn) in _d_plan(n_layers):
+        keys.append(f"model.{i}.weight")
+        if has_bias:
+            keys.append(f"model.{i}.bias")
+        if bn:
+            keys += [f"model.{i + 1}.{n}" for n in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+    return keys
+
+
+def nlayer_d_state(input_nc: int, ndf: int = 64, n_layers: int = 3, seed: int = 0) -> State:
+    """torch-default init (the reference never re-initialises D)."""
+    g = torch.Generator().manual_seed(seed)
+    chans = [input_nc, ndf]
+    for n in range(1, n_layers):
+        chans.append(ndf * min(2 ** n, 8))
+    chans.append(ndf * min(2 ** n_layers, 8))
+    chans.append(1)
+    sd: State = {}
+    for li, (i, _s, has_bias, bn) in enumerate(_d_plan(n_layers)):
+        ci, co = chans[li], chans[li + 1]
+        sd[f"model.{i}.weight"] = _default_uniform((co, ci, 4, 4), ci * 16, g)
+        if has_bias:
+            sd[f"model.{i}.bias"] = _default_uniform((co,), ci * 16, g)
+        if bn:
+            sd[f"model.{i + 1}.weight"] = torch.ones(co)
+            sd[f"model.{i + 1}.bias"] = torch.zeros(co)
+            sd[f"model.{i + 1}.running_mean"] = torch.zeros(co)
+            sd[f"model.{i + 1}.running_var"] = torch.ones(co)
+            sd[f"model.{i + 1}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    return sd
+
+
+def nlayer_d_forward(sd: State, x: Tensor, training: bool = True) -> Tensor:
+    """NLayerDiscriminator.forward, model/model.py:637-639.  In training mode the
+    BatchNorm layers use batch statistics and update running_mean/var/
+    num_batches_tracked *in place* in ``sd`` exactly like nn.BatchNorm2d."""
+    conv_ids = sorted({int(k.split(".")[1]) for k in sd if k.endswith(".weight") and sd[k].dim() == 4})
+    last = conv_ids[-1]
+    strides = {}
+    # stride 2 for every conv except the last two (model/model.py:612,620,628,634)
+    for n, i in enumerate(conv_ids):
+        strides[i] = 2 if n < len(conv_ids) - 2 else 1
+    h = x
+    for i in conv_ids:
+        h = F.conv2d(h, sd[f"model.{i}.weight"], sd.get(f"model.{i}.bias"), strides[i], 1)
+        if i == last:
+            break
+        if f"model.{i + 1}.running_mean" in sd:
+            j = i + 1
+            if training:
+                sd[f"model.{j}.num_batches_tracked"] += 1
+            h = F.batch_norm(h, sd[f"model.{j}.running_mean"], sd[f"model.{j}.running_var"],
+                             sd[f"model.{j}.weight"], sd[f"model.{j}.bias"], training, BN_MOMENTUM, BN_EPS)
+        h = _lrelu(h)
+    return h
+
+
+# ---------------------------------------------------------------------------
+# Losses (reference src/losses.py:95-147, src/train.py:67-128)
+# ---------------------------------------------------------------------------
+def l1_loss(a: Tensor, b: Tensor) -> Tensor:
+    """losses.L1Loss.forward, losses.py:103-105: mean |a-b|."""
+    return (a - b).abs().mean()
+
+
+def mse_loss(a: Tensor, b: Tensor) -> Tensor:
+    """losses.MSELoss.forward, losses.py:131-133: mean (a-b)^2."""
+    return ((a - b) ** 2).mean()
+
+
+def psnr(a: Tensor, b: Tensor) -> Tensor:
+    """losses.PSNRLoss.forward, losses.py:144-147: 10*log10(1/mse)."""
+    return 10.0 * torch.log10(1.0 / mse_loss(a, b))
+
+
+def gan_loss(pred: Tensor, target_is_real: bool, real_label: float = 1.0, fake_label: float = 0.0) -> Tensor:
+    """GANLoss('lsgan').__call__, train.py:98-127: MSE against an expanded scalar label."""
+    t = real_label if target_is_real else fake_label
+    return ((pred - t) ** 2).mean()
+
+
+# ---------------------------------------------------------------------------
+# In-step preprocessing (reference src/trainCas.py:82-112, src/train.py:243-258,382)
+# ---------------------------------------------------------------------------
+def rgb_to_gray(x: Tensor) -> Tensor:
+    """trainCas.py:85-87: Y = 0.2125 R + 0.7154 G + 0.0721 B, keeps a channel dim."""
+    return 0.2125 * x[:, 0:1] + 0.7154 * x[:, 1:2] + 0.0721 * x[:, 2:3]
+
+
+def bilinear_down(x: Tensor, up: int) -> Tensor:
+    """F.interpolate(scale_factor=1/up, mode='bilinear') (align_corners=False, no
+    antialias), trainCas.py:89-90.  For integer ``up`` and sizes divisible by it
+    this is the mean of the centre 2x2 of each up x up block (up even)."""
+    return F.interpolate(x, scale_factor=1.0 / up, mode="bilinear")
+
+
+def nearest_down(x: Tensor, up: int) -> Tensor:
+    """F.interpolate(scale_factor=1/up) default mode (nearest), train.py:243,382."""
+    return F.interpolate(x, scale_factor=1.0 / up, mode="nearest")
+
+
+def cas_forward_sr_inputs(real_b: Tensor, up: int) -> Tuple[Tensor, Tensor]:
+    """CasSRC.forwardSR input preparation, trainCas.py:82-90 -> (real_BC, real_BA)."""
+    bc = rgb_to_gray(real_b)
+    return bc, bilinear_down(bc, up)
+
+
+def cosine_lr_sequence(lr0: float, epochs: int, t_max: int) -> List[float]:
+    """CasSRC.update_lr with 'cosine' (trainCas.py:45-61): a *fresh*
+    CosineAnnealingLR is built every epoch and stepped once, which multiplies the
+    current lr by (1+cos(pi/T_max))/2 each epoch."""
+    f = (1.0 + math.cos(math.pi / t_max)) / 2.0
+    out, lr = [], lr0
+    for _ in range(epochs):
+        lr *= f
+        out.append(lr)
+    return out
+
+
+class ImagePoolOracle:
+    """ImagePool.query, train.py:36-64 (pool of previously generated images, p=0.5 swap)."""
+
+    def __init__(self, pool_size: int, rng: Optional[random.Random] = None):
+        self.pool_size, self.images, self.rng = pool_size, [], rng or random
+
+    def query(self, images: Tensor) -> Tensor:
+        if self.pool_size == 0:
+            return images
+        out = []
+        for im in images:
+            im = im.detach().unsqueeze(0)
+            if len(self.images) < self.pool_size:
+                self.images.append(im)
+                out.append(im)
+            elif self.rng.uniform(0, 1) > 0.5:
+                k = self.rng.randint(0, self.pool_size - 1)
+                out.append(self.images[k].clone())
+                self.images[k] = im
+            else:
+                out.append(im)
+        return torch.cat(out, 0)
+
+
+# ---------------------------------------------------------------------------
+# HR->LR generator G_B ("RDDBNetA").  NO SOURCE IN THE REFERENCE (train.py:11,173
+# import a name defined nowhere) -> build-defined, PARITY UNPINNED vs reference.
+# Mirror of RDDBNet with one strided 3x3 s2 conv (+LeakyReLU) per /2 stage placed
+# *before* the trunk so the trunk runs at LR.
+# ---------------------------------------------------------------------------
+def rddbneta_forward(sd: State, x: Tensor, down_factor: int) -> Tensor:
+    nb = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("RRDB_trunk."))
+    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    for s in range(int(math.log2(down_factor)) if down_factor > 1 else 0):
+        fea = _lrelu(F.conv2d(fea, sd[f"down_layers.{2 * s}.weight"], sd[f"down_layers.{2 * s}.bias"], 2, 1))
+    t = fea
+    for i in range(nb):
+        t = rrdb_forward(sd, f"RRDB_trunk.{i}.", t)
+    t = F.conv2d(t, sd["trunk_conv.weight"], sd["trunk_conv.bias"], 1, 1)
+    fea = fea + t
+    return F.conv2d(fea, sd["conv_last.weight"], None, 1, 1)
+
+
+def rddbneta_state(in_ch: int, ou_ch: int, down: int, nf: int = 64, nb: int = 3, gc: int = 32, seed: int = 0) -> State:
+    base = rddbnet_state(in_ch, ou_ch, 1, nf, nb, gc, seed)
+    g = torch.Generator().manual_seed(seed + 7919)
+    sd: State = {}
+    for k, v in base.items():
+        sd[k] = v
+        if k == "conv_first.bias":
+            for s in range(int(math.log2(down)) if down > 1 else 0):
+                sd[f"down_layers.{2 * s}.weight"] = _kaiming_normal_fan_out((nf, nf, 3, 3), g)
+                sd[f"down_layers.{2 * s}.bias"] = _default_uniform((nf,), nf * 9, g)
+    return sd
+
+
+# ---------------------------------------------------------------------------
+# Paired G+D training step (BASELINE config 1/2):
+#   G-step: fake=G(x); loss_G = lsgan(D(fake),1) + 10*L1(fake,y); Adam(G, 1e-4, b1 .5)
+#   D-step: loss_D = .5*(lsgan(D(y),1)+lsgan(D(fake.detach()),0)); Adam(D, 1e-5, b1 .5)
+# restating train.py:262-340 (backward_D_basic / backward_G / optimize_parameters)
+# for one generator/discriminator pair.
+# ---------------------------------------------------------------------------
+class PairedStepState:
+    def __init__(self, g_sd: State, d_sd: State, up: int, lambda_l1: float = 10.0,
+                 lr_g: float = 1e-4, lr_d: float = 1e-5, beta1: float = 0.5):
+        self.up, self.lambda_l1 = up, lambda_l1
+        self.g = {k: v.clone().requires_grad_(True) for k, v in g_sd.items()}
+        self.d = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                  for k, v in d_sd.items()}
+        self.g_params = list(self.g.values())
+        self.d_params = [v for v in self.d.values() if v.requires_grad]
+        self.opt_g = torch.optim.Adam(self.g_params, lr=lr_g, betas=(beta1, 0.999))
+        self.opt_d = torch.optim.Adam(self.d_params, lr=lr_d, betas=(beta1, 0.999))
+
+
+def make_paired_state(in_ch=3, ou_ch=3, up=2, nf=64, nb=1, gc=32, ndf=64, n_layers=3, seed=0) -> PairedStepState:
+    return PairedStepState(rddbnet_state(in_ch, ou_ch, up, nf, nb, gc, seed),
+                           nlayer_d_state(ou_ch, ndf, n_layers, seed + 1), up)
+
+
+def paired_step(st: PairedStepState, x: Tensor, y: Tensor) -> Dict[str, float]:
+    # ---- G step (train.py:330-333, D frozen) ----
+    for p in st.d_params:
+        p.requires_grad_(False)
+    st.opt_g.zero_grad()
+    fake = rddbnet_forward(st.g, x, st.up)
+    loss_gan = gan_loss(nlayer_d_forward(st.d, fake, True), True)
+    loss_l1 = l1_loss(fake, y)
+    loss_g = loss_gan + st.lambda_l1 * loss_l1
+    loss_g.backward()
+    st.opt_g.step()
+    # ---- D step (train.py:336-340, 262-280) ----
+    for p in st.d_params:
+        p.requires_grad_(True)
+    st.opt_d.zero_grad()
+    loss_d = 0.5 * (gan_loss(nlayer_d_forward(st.d, y, True), True)
+                    + gan_loss(nlayer_d_forward(st.d, fake.detach(), True), False))
+    loss_d.backward()
+    st.opt_d.step()
+    return {"loss_G": float(loss_g), "loss_G_GAN": float(loss_gan), "loss_L1": float(loss_l1), "loss_D": float(loss_d)}
+
+
+# ---------------------------------------------------------------------------
+# Full cycle step (reference src/train.py:228-340, params :344-361).  G_A = RDDBNet
+# (LR->HR), G_B = rddbneta (HR->LR, build-defined), D_A on HR, D_B on LR.
+# ---------------------------------------------------------------------------
+class CycleState:
+    def __init__(self, ga: State, gb: State, da: State, db: State, up: int, pool_size: int = 4,
+                 lr: float = 1e-4, lr_d: float = 1e-5, beta1: float = 0.5,
+                 lambda_a: float = 10.0, lambda_b: float = 10.0, lambda_idt: float = 1.0, seed: int = 0):
+        self.up = up
+        self.lam = (lambda_a, lambda_b, lambda_idt)
+        req = lambda sd: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                          for k, v in sd.items()}
+        self.ga, self.gb, self.da, self.db = req(ga), req(gb), req(da), req(db)
+        gp = list(self.ga.values()) + list(self.gb.values())
+        self.dp = [v for v in list(self.da.values()) + list(self.db.values()) if v.requires_grad]
+        self.opt_g = torch.optim.Adam(gp, lr=lr, betas=(beta1, 0.999))        # train.py:191
+        self.opt_d = torch.optim.Adam(self.dp, lr=lr_d, betas=(beta1, 0.999))  # train.py:192
+        rng = random.Random(seed)
+        self.pool_a, self.pool_b = ImagePoolOracle(pool_size, rng), ImagePoolOracle(pool_size, rng)
+
+
+def make_cycle_state(up=2, nf=64, nb=1, gc=32, ndf=64, n_layers=3, seed=0) -> CycleState:
+    return CycleState(rddbnet_state(3, 3, up, nf, nb, gc, seed), rddbneta_state(3, 3, up, nf, nb, gc, seed + 1),
+                      nlayer_d_state(3, ndf, n_layers, seed + 2), nlayer_d_state(3, ndf, n_layers, seed + 3), up, seed=seed)
+
+
+def cycle_step(st: CycleState, real_a: Tensor, real_b: Tensor) -> Dict[str, float]:
+    la, lb, lidt = st.lam
+    GA = lambda t: rddbnet_forward(st.ga, t, st.up)
+    GB = lambda t: rddbneta_forward(st.gb, t, st.up)
+    # forward, train.py:228-249 (opt.net == '1' branch: 3-channel both sides, nearest resampling)
+    fake_b = GA(real_a); recl_a = GB(fake_b)
+    fake_a = GB(real_b); recl_b = GA(fake_a)
+    iden_a = GA(nearest_down(real_b, st.up))
+    iden_b = GB(F.interpolate(real_a, scale_factor=st.up))
+    # G step, train.py:292-333
+    for p in st.dp:
+        p.requires_grad_(False)
+    st.opt_g.zero_grad()
+    l_iden_a = l1_loss(iden_a, real_b) * lb / 2 * lidt
+    l_iden_b = l1_loss(iden_b, real_a) * la / 2 * lidt
+    l_g_a = gan_loss(nlayer_d_forward(st.da, fake_b, True), True)
+    l_g_b = gan_loss(nlayer_d_forward(st.db, fake_a, True), True)
+    l_cyc_a = l1_loss(recl_a, real_a) * la * 0.5
+    l_cyc_b = l1_loss(recl_b, real_b) * lb * 0.5
+    loss_g = (l_g_a + l_g_b) + l_cyc_a + l_cyc_b + l_iden_a + l_iden_b
+    loss_g.backward()
+    st.opt_g.step()
+    # D step, train.py:262-290,336-340
+    for p in st.dp:
+        p.requires_grad_(True)
+    st.opt_d.zero_grad()
+    fb = st.pool_b.query(fake_b)
+    l_d_a = 0.5 * (gan_loss(nlayer_d_forward(st.da, real_b, True), True) + gan_loss(nlayer_d_forward(st.da, fb.detach(), True), False))
+    l_d_a.backward()
+    fa = st.pool_a.query(fake_a)
+    l_d_b = 0.5 * (gan_loss(nlayer_d_forward(st.db, real_a, True), True) + gan_loss(nlayer_d_forward(st.db, fa.detach(), True), False))
+    l_d_b.backward()
+    st.opt_d.step()
+    return {"loss_G": float(loss_g), "loss_D_A": float(l_d_a), "loss_D_B": float(l_d_b),
+            "loss_cycle": float(l_cyc_a + l_cyc_b), "loss_iden": float(l_iden_a + l_iden_b), "loss_G_GAN": float(l_g_a + l_g_b)}

@@ -1,0 +1,164 @@
+"""CPU: the oracle restatement vs the golden vectors produced by the imported
+reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, sub, rel_err
+
+TOL = 2e-5   # fp32 accumulation-order noise only; the restatement calls the same ATen ops
+
+
+def _req(sd):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+            for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("tag", ["rdb_tiny", "rdb_full"])
+def test_rdb(tag):
+    g = load_golden(tag)
+    sd = _req(sub(g, "sd/"))
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.rdb_forward(sd, "", x)
+    loss = oracle.l1_loss(y, torch.from_numpy(g["t"]))
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert rel_err(x.grad, g["dx"]) < TOL
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < TOL, k
+
+
+@pytest.mark.parametrize("tag", ["rddbnet_x2", "rddbnet_x4", "rddbnet_x2_w32"])
+def test_rddbnet(tag):
+    g = load_golden(tag)
+    ic, oc, up, nf, nb, gc = [int(v) for v in g["cfg"]]
+    sd = _req(sub(g, "sd/"))
+    assert list(sd.keys()) == oracle.rddbnet_keys(nb, up)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.rddbnet_forward(sd, x, up)
+    loss = oracle.l1_loss(y, torch.from_numpy(g["t"]))
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert rel_err(x.grad, g["dx"]) < TOL
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < TOL, k
+    # state generator has the reference's key order and shapes
+    mine = oracle.rddbnet_state(ic, oc, up, nf, nb, gc)
+    assert [(k, tuple(v.shape)) for k, v in mine.items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+
+
+def test_upscale():
+    g = load_golden("upscale_x4")
+    w = sub(g, "sd/")
+    sd = {f"upscale_layers.{k}": v.clone().requires_grad_(True) for k, v in w.items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    h = x
+    for s in range(2):
+        h = torch.nn.functional.leaky_relu(
+            torch.nn.functional.conv_transpose2d(h, sd[f"upscale_layers.{2*s}.weight"], None, 2, 0), 0.2)
+    (h * torch.linspace(-1, 1, h.numel()).view_as(h)).sum().backward()
+    assert rel_err(h, g["y"]) < TOL
+    assert rel_err(x.grad, g["dx"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["nlayerd_3", "nlayerd_2"])
+def test_nlayer_d(tag):
+    g = load_golden(tag)
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    sd = _req(sub(g, "sd/"))
+    assert list(sd.keys()) == oracle.nlayer_d_keys(nl)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.nlayer_d_forward(sd, x, True)
+    loss = oracle.gan_loss(y, True)
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert rel_err(x.grad, g["dx"]) < 1e-4
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < 1e-4, k
+    for k, v in sub(g, "sd_after/").items():
+        assert rel_err(sd[k].double(), v.double()) < 1e-5, k
+    with torch.no_grad():
+        assert rel_err(oracle.nlayer_d_forward(sd, x, False), g["y_eval"]) < TOL
+    mine = oracle.nlayer_d_state(ic, ndf, nl)
+    assert [(k, tuple(v.shape)) for k, v in mine.items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+
+
+def test_losses():
+    g = load_golden("losses")
+    b = torch.from_numpy(g["b"])
+    for name, fn in (("l1", oracle.l1_loss), ("mse", oracle.mse_loss), ("psnr", oracle.psnr)):
+        a = torch.from_numpy(g["a"]).requires_grad_(True)
+        v = fn(a, b)
+        v.backward()
+        assert abs(float(v) - float(g[name])) < 1e-5 * max(1.0, abs(float(g[name])))
+        assert rel_err(a.grad, g[name + "_da"]) < 1e-5
+    for name, real in (("gan_real", True), ("gan_fake", False)):
+        a = torch.from_numpy(g["a"]).requires_grad_(True)
+        v = oracle.gan_loss(a, real)
+        v.backward()
+        assert abs(float(v) - float(g[name])) < 1e-6
+        assert rel_err(a.grad, g[name + "_da"]) < 1e-5
+
+
+def test_preproc():
+    g = load_golden("preproc")
+    img = torch.from_numpy(g["img"])
+    gray = oracle.rgb_to_gray(img)
+    assert rel_err(gray, g["gray"]) < 1e-6
+    for up in (2, 4):
+        assert rel_err(oracle.bilinear_down(gray, up), g[f"bil_down{up}"]) < 1e-6
+        assert rel_err(oracle.nearest_down(img, up), g[f"near_down{up}"]) < 1e-6
+
+
+def test_cas_step_sr_half():
+    """SR half of CasSRC.optimize_parameters (trainCas.py:133-145) reproduced from the
+    stored initial state: loss_SR, fake_BC, post-Adam weights, lr after update_lr."""
+    g = load_golden("cas_step")
+    sd = _req(sub(g, "sr0/"))
+    realB = torch.from_numpy(g["realB"])
+    bc, ba = oracle.cas_forward_sr_inputs(realB, 2)
+    assert rel_err(bc, g["real_BC"]) < 1e-6 and rel_err(ba, g["real_BA"]) < 1e-6
+    lr = oracle.cosine_lr_sequence(1e-4, 1, 50)[0]
+    assert abs(lr - float(g["lr_after"])) < 1e-12
+    opt = torch.optim.Adam(list(sd.values()), lr=lr)
+    fake = oracle.rddbnet_forward(sd, ba, 2)
+    loss = oracle.l1_loss(fake, bc)
+    loss.backward()
+    opt.step()
+    assert rel_err(fake, g["fake_BC"]) < TOL
+    assert abs(float(loss) - float(g["loss_SR"])) < 1e-6
+    assert abs(float(oracle.psnr(fake.detach(), bc)) - float(g["psnr_SR"])) < 1e-3
+    for k, v in sub(g, "sr1/").items():
+        assert rel_err(sd[k], v) < 1e-5, k
+
+
+def test_paired_step():
+    g = load_golden("paired_step")
+    st = oracle.PairedStepState(sub(g, "g0/"), sub(g, "d0/"), up=2)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for step in range(2):
+        out = oracle.paired_step(st, x, y)
+        for k in ("loss_G", "loss_D", "loss_G_GAN", "loss_L1"):
+            assert abs(out[k] - float(g[f"{k}_{step}"])) < 2e-5 * max(1.0, abs(float(g[f"{k}_{step}"]))), (k, step)
+    for k, v in sub(g, "g1/").items():
+        assert rel_err(st.g[k], v) < 1e-4, k
+    for k, v in sub(g, "d1/").items():
+        if v.is_floating_point():
+            assert rel_err(st.d[k], v) < 1e-4, k
+        else:
+            assert int(st.d[k]) == int(v)
+
+
+def test_cycle_step_runs():
+    """Full-cycle restatement (train.py:228-340); G_B is build-defined so this is a
+    self-consistency check only ("parity unpinned" for G_B)."""
+    st = oracle.make_cycle_state(up=2, nf=16, nb=1, gc=8, ndf=16)
+    torch.manual_seed(1)
+    a, b = torch.rand(2, 3, 32, 32), torch.rand(2, 3, 64, 64)
+    out1 = oracle.cycle_step(st, a, b)
+    out2 = oracle.cycle_step(st, a, b)
+    assert all(np.isfinite(v) for v in out1.values())
+    assert out2["loss_cycle"] < out1["loss_cycle"] * 1.5
