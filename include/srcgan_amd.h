@@ -1,0 +1,213 @@
+/*
+ * srcgan_amd.h -- C ABI of the MI355X (gfx950) native SRCGAN training hot path.
+ *
+ * Drop-in boundary.  The reference (huster-wgm/SRCGAN) has no native code: its
+ * hot path is torch.nn modules executed by ATen.  Each
+ * entry point below replaces the ATen work behind one reference call site; the
+ * Python host (srcgan_amd/) mirrors the reference's nn.Module / loss classes and
+ * reaches these symbols through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless said
+ *     otherwise; `stream` is a hipStream_t passed as void*.
+ *   - activations are NHWC ("channels-last") with an explicit channel stride
+ *     (`cs`, elements per pixel) and channel offset (`coff`) so a convolution
+ *     can read a channel prefix of a dense-block buffer and write its own
+ *     channel slice -- this is what removes torch.cat (rddb.py:64-67).
+ *   - dtype: SRCGAN_F32 (exact f32 MFMA, parity mode) or SRCGAN_BF16 (bf16
+ *     storage + bf16 MFMA, f32 accumulate; perf mode).
+ *   - return value: 0 on success, non-zero on error; srcgan_last_error() gives
+ *     the message (thread-local).  Shape/alignment violations are rejected on
+ *     the host before any launch.
+ */
+#ifndef SRCGAN_AMD_H
+#define SRCGAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRCGAN_F32 0
+#define SRCGAN_BF16 1
+
+int srcgan_version(void);
+const char* srcgan_last_error(void);
+/* bytes of one element of dtype */
+int srcgan_dtype_size(int dtype);
+
+/* ---------------------------------------------------------------------------
+ * Layout: NCHW f32 (the reference's tensor format, dataset.py:131) <-> NHWC.
+ * to_nhwc writes channels [0,C) and zero-fills [C,cs).
+ * ------------------------------------------------------------------------- */
+int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W,
+                            int cs, int dtype, void* stream);
+int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W,
+                            int cs, int coff, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight packing.  Canonical torch weights stay f32 [Cout,Cin,kh,kw] (Conv2d) or
+ * [Cin,Cout,kh,kw] (ConvTranspose2d) so state_dict / Adam are untouched; kernels
+ * read a packed copy  Wp[row_tile][k_chunk][tap][row][k]  (dtype, zero padded).
+ * packed(row r, k, tap (ty,tx)) = w[off + r*sr + k*sk + ty*sty + tx*stx].
+ * The same routine produces forward, flipped/transposed dgrad and stride-2
+ * parity-class packs by choice of strides.
+ * ------------------------------------------------------------------------- */
+size_t srcgan_packed_weight_bytes(int rows, int kdim, int ntaps, int dtype);
+int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, int tys, int txs,
+                       long sr, long sk, long sty, long stx, long off, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Implicit-GEMM convolution (forward form).  Replaces aten::convolution for
+ *   rddb.py:52-58 (3x3 s1), rddb.py:28-38 (k2 s2 deconv = 4 x 1x1 + pixel
+ *   shuffle store), model/model.py:612-634 (4x4 s2 / s1), and -- with packed
+ *   transposed weights -- every dgrad of aten::convolution_backward.
+ *
+ *   v   = alpha * (conv(x)[co] + bias[co])
+ *       + (co < r1_cend ? beta1 * r1 : 0) + (co < r2_cend ? beta2 * r2 : 0)
+ *   v   = act ? leaky_relu(v, slope) : v
+ *   v  *= (co >= mz_c0 && mz) ? (mz > 0 ? 1 : mslope) : 1      (LeakyReLU' mask)
+ *   y[b, oy*os+oa, ox*os+ob, ycoff+co] = v
+ * r1/r2/mz are indexed like y.  r1 may alias y (in-place accumulate).
+ * ------------------------------------------------------------------------- */
+typedef struct srcgan_conv_desc {
+    const void* x; const void* wp; const float* bias; void* y;
+    const void* r1; const void* r2; const void* mz;
+    int dtype;
+    int kh, kw, stride;
+    int B, H, W, Cin, x_cs, x_coff;         /* input tensor; Cin = channels read (multiple of 16B piece) */
+    int OH, OW, Cout;                       /* conv output extent and true Cout */
+    int YH, YW, y_cs, y_coff;               /* output tensor extent (after os scaling) */
+    int pad_y, pad_x, os, oa, ob;
+    int r1_cs, r1_coff, r1_cend;
+    int r2_cs, r2_coff, r2_cend;
+    int mz_cs, mz_coff, mz_c0;
+    float alpha, beta1, beta2, slope, mslope;
+    int act;
+} srcgan_conv_desc;
+int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight gradient (the wgrad third of aten::convolution_backward):
+ *   dW[co, tap, ci] = alpha * sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*s+ky-pad, ox*s+kx-pad, ci]
+ * computed split-K over pixel ranges into an f32 slab, then reduced in a fixed
+ * order (deterministic) and scattered to the canonical f32 gradient:
+ *   grad[off + co*sr + ci*sk + ky*sty + kx*stx] (=|+=) value
+ * ------------------------------------------------------------------------- */
+typedef struct srcgan_wgrad_desc {
+    const void* dy; const void* x; float* slab; float* grad;
+    int dtype;
+    int kh, kw, stride;
+    int B, H, W, Cin, x_cs, x_coff;         /* x tensor; Cin = true input channels */
+    int OH, OW, Cout, dy_cs, dy_coff;       /* dy tensor; Cout = true output channels */
+    int pad_y, pad_x;
+    int nsplit;
+    long sr, sk, sty, stx, off;
+    float alpha;
+    int accumulate;
+} srcgan_wgrad_desc;
+/* slab bytes needed for (Cout,Cin,kh,kw,nsplit) */
+size_t srcgan_conv_wgrad_slab_bytes(int Cout, int Cin, int kh, int kw, int nsplit);
+/* a good nsplit for this problem (fills the chip, bounded slab) */
+int srcgan_conv_wgrad_nsplit(int B, int OH, int OW, int Cout, int Cin, int stride);
+int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Column reductions over pixels (deterministic two-stage):
+ *   mode 0: out0[c] = scale * sum a[p,c]                         (bias grad; BN mean)
+ *   mode 1: out0[c] = scale * sum (a[p,c]-m[c])^2                (BN variance)
+ *   mode 2: out0[c] = sum g[p,c] ; out1[c] = sum g[p,c]*(z[p,c]-m[c])*rstd[c]   (BN backward)
+ * scratch: 2*nblk*C floats, nblk = srcgan_col_reduce_blocks(npix).
+ * ------------------------------------------------------------------------- */
+int srcgan_col_reduce_blocks(long npix);
+int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, const void* z, int z_cs, int z_coff,
+                      const float* m, const float* rstd, long npix, int C, float scale,
+                      float* out0, float* out1, float* scratch, int dtype, void* stream);
+
+/* BatchNorm2d(train)+LeakyReLU (model/model.py:622-623,630-631), NHWC.
+ * bn_finalize: mean/var -> rstd, running-stat update (momentum .1, unbiased var), nbt++.
+ * bn_apply:    y = lrelu(gamma*(z-mean)*rstd+beta)
+ * bn_bwd_apply:dz = gamma*rstd*(g - sum_g/N - xhat*sum_gx/N)   (g already holds dy*lrelu'(y)) */
+int srcgan_bn_finalize(const float* mean, const float* var, float* rstd, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, int C, long count,
+                       float momentum, float eps, void* stream);
+int srcgan_bn_eval_rstd(const float* running_var, float* rstd, int C, float eps, void* stream);
+int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, long npix, int C, int cs, float slope, int dtype, void* stream);
+int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mean, const float* rstd,
+                        const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
+                        int dtype, void* stream);
+
+/* y[p, ycoff+c] = (y + x[p, xcoff+c]) * (mz ? (mz[p, mzcoff+c] > 0 ? 1 : mslope) : 1) for c < C
+ * (residual gradient joins; optional LeakyReLU' of the tensor the gradient belongs to) */
+int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
+                       const void* mz, int mz_cs, int mz_coff, float mslope, long npix, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Loss reductions on flat f32 arrays (replace aten::l1_loss / mse_loss and their
+ * backward; losses.py:95-147, train.py:67-128).  out: device f32 scalar.
+ *   kind 0: mean |a-b|          kind 1: mean (a-b)^2      kind 2: mean (a-label)^2
+ * bwd: da[i] = gscale * d/da of the mean (gscale = upstream grad, device scalar * host scale)
+ * scratch: srcgan_loss_scratch_floats() floats.
+ * ------------------------------------------------------------------------- */
+int srcgan_loss_scratch_floats(void);
+int srcgan_loss_fwd(int kind, const float* a, const float* b, float label, long n, float* out,
+                    float* scratch, void* stream);
+int srcgan_loss_bwd(int kind, const float* a, const float* b, float label, long n, const float* gout,
+                    float gscale, float* da, void* stream);
+/* psnr = 10*log10(1/mse) from a device mse scalar (losses.py:144-147) */
+int srcgan_psnr_from_mse(const float* mse, float* out, void* stream);
+
+/* In-step preprocessing (trainCas.py:85-90): gray = .2125R+.7154G+.0721B (NCHW f32 in/out),
+ * bilinear x(1/up) with align_corners=False == mean of the centre 2x2 of each up x up block. */
+int srcgan_rgb_to_gray(const float* rgb, float* gray, int B, int H, int W, void* stream);
+int srcgan_bilinear_down(const float* src, float* dst, int B, int C, int H, int W, int up, void* stream);
+int srcgan_nearest_resize(const float* src, float* dst, int B, int C, int H, int W, int OH, int OW, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Whole-network passes (C++ sequencing of the kernels above; one call per
+ * nn.Module.forward / autograd backward).
+ *
+ * RDDBNet (rddb.py:85-114).  params/grads: arrays of device f32 pointers in
+ * state_dict order (conv_first.weight, conv_first.bias, RRDB_trunk.0.RDB1.conv1.weight, ...).
+ * ------------------------------------------------------------------------- */
+typedef struct srcgan_rddbnet_cfg {
+    int in_ch, out_ch, up, nf, nb, gc;
+    int B, H, W;
+    int dtype;
+    int down;          /* 0: RDDBNet (LR->HR, deconv up-sampler).  >0: HR->LR mirror
+                          ("RDDBNetA", build-defined): `down` = /2^k factor, strided 3x3 convs */
+} srcgan_rddbnet_cfg;
+int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);
+size_t srcgan_rddbnet_ws_bytes(const srcgan_rddbnet_cfg* c);        /* forward workspace (kept for backward) */
+size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c);
+int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
+                           void* ws, float* y_nchw, void* stream);
+/* grads[i] may be NULL (parameter frozen); dx_nchw may be NULL */
+int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
+                            void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
+
+/* NLayerDiscriminator (model/model.py:595-639).  params in state_dict order of the
+ * learnable tensors: conv0.w, conv0.b, [conv_l.w, bn_l.gamma, bn_l.beta]*, conv_last.w, conv_last.b.
+ * bn_state: per BN layer running_mean, running_var (f32) ; nbt: int64 counters. */
+typedef struct srcgan_nlayerd_cfg {
+    int in_ch, ndf, n_layers;
+    int B, H, W;
+    int dtype;
+    int training;
+} srcgan_nlayerd_cfg;
+int srcgan_nlayerd_num_params(const srcgan_nlayerd_cfg* c);
+int srcgan_nlayerd_out_hw(const srcgan_nlayerd_cfg* c, int* oh, int* ow);
+size_t srcgan_nlayerd_ws_bytes(const srcgan_nlayerd_cfg* c);
+size_t srcgan_nlayerd_bwd_scratch_bytes(const srcgan_nlayerd_cfg* c);
+int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, const float* const* params,
+                           float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw, void* stream);
+int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
+                            void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCGAN_AMD_H */

@@ -1,0 +1,56 @@
+// Shared device/host helpers for the gfx950 SRCGAN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/srcgan_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Per-dtype constants.  A "piece" is 16 bytes; a K-chunk is 64 bytes of channels
+// per pixel (16 f32 or 32 bf16) so both dtypes share one LDS byte layout.
+template <typename T> struct DT;
+template <> struct DT<float>  { static constexpr int id = SRCGAN_F32;  static constexpr int EPP = 4; static constexpr int KCE = 16; };
+template <> struct DT<__bf16> { static constexpr int id = SRCGAN_BF16; static constexpr int EPP = 8; static constexpr int KCE = 32; };
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
+
+// 4 consecutive channels <-> f32 registers (8-byte bf16 / 16-byte f32 accesses)
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load4<__bf16>(const __bf16* p, float (&v)[4]) {
+    bf16x4 t = *(const bf16x4*)p; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = t;
+}
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const float (&v)[4]) {
+    bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; *(bf16x4*)p = t;
+}
+
+// ---------------------------------------------------------------- host side
+void srcgan_set_error(const char* fmt, ...);
+#define SG_FAIL(...) do { srcgan_set_error(__VA_ARGS__); return 1; } while (0)
+#define SG_REQUIRE(cond, ...) do { if (!(cond)) { srcgan_set_error(__VA_ARGS__); return 1; } } while (0)
+#define SG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    srcgan_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+#define SG_LAUNCH_CHECK() SG_HIP(hipGetLastError())
+#define SG_TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,278 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC, halo tile staged once in LDS and
+// reused by every filter tap, MFMA contraction over (tap, channel-chunk), fused epilogue
+// (bias, scale, two residuals, LeakyReLU, LeakyReLU' mask, pixel-shuffle store).
+//
+// Replaces aten::convolution / the dgrad half of aten::convolution_backward behind
+//   reference src/model/rddb.py:52-58,63-68 (RDB 3x3 convs + "cat" + 0.2*x5+x),
+//   rddb.py:28-38,93-97 (ConvTranspose2d k2 s2 == 4 x [1x1 conv -> strided store]),
+//   src/model/model.py:612-634 (PatchGAN 4x4 s2 / s1 convs).
+//
+// GEMM orientation: D[M = Cout][N = pixels] so that each lane of the 32x32 MFMA result holds
+// 4 *consecutive output channels* of one pixel -> 8/16-byte epilogue loads and stores in NHWC.
+//   A operand (M x K): packed weights, row = cout, k = cin within the chunk
+//   B operand (K x N): LDS halo tile, col = 32 consecutive output pixels of one row
+// LDS image: one pixel (or one weight row) = 64 B of channels padded to 80 B -> ds_read_b128
+// of 32 consecutive pixels is bank-conflict free (stride 5 slots of 16 B, coprime with 16).
+// Both dtypes use the same byte layout: 64 B = 32 bf16 (2 x mfma_32x32x16_bf16 k-steps)
+//                                            = 16 f32  (8 x mfma_32x32x2_f32).
+#include "common.h"
+#include <type_traits>
+
+struct ConvP {
+    const void* x; const void* wp; const float* bias; void* y;
+    const void* r1; const void* r2; const void* mz;
+    int B, H, W, Cin, xCs, xcoff;
+    int OH, OW, Cout, YH, YW, yCs, ycoff;
+    int pad_y, pad_x, os, oa, ob;
+    int r1Cs, r1coff, r1cend, r2Cs, r2coff, r2cend, mzCs, mzcoff, mzc0;
+    float alpha, beta1, beta2, slope, mslope;
+    int act, vec, nchunk, tiles_x, tiles_y;
+};
+
+
+template <typename T, int KH, int KW, int S, int MT, int PT, bool WPK>
+__global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
+    using D = DT<T>;
+    constexpr int TH = 4 * PT, TW = 32;
+    constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
+    constexpr int COT = 32 * MT, NTAP = KH * KW, PIXB = 80;
+    constexpr int WROWS = (WPK ? KW : NTAP) * COT;
+    constexpr int NPH = IHT * IWT * 4;     // 16-byte pieces of the halo tile
+    constexpr int NPW = WROWS * 4;         // 16-byte pieces of one weight stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_h = smem;
+    char* lds_w = smem + IHT * IWT * PIXB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int ct = blockIdx.y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int gy0 = oy0 * S - p.pad_y, gx0 = ox0 * S - p.pad_x;
+
+    f32x16 acc[MT][PT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < PT; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+
+    const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+    const char* wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
+
+    for (int c = 0; c < p.nchunk; ++c) {
+        __syncthreads();   // all waves are done reading the previous chunk
+        // ---- stage the input halo tile for this channel chunk (zero outside the image / past Cin)
+#pragma unroll
+        for (int it = 0; it < (NPH + 255) / 256; ++it) {
+            const int pc = it * 256 + tid;
+            if (pc < NPH) {
+                const int pix = pc >> 2, part = pc & 3;
+                const int iy = pix / IWT, ix = pix - iy * IWT;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                const int ch = c * D::KCE + part * D::EPP;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.Cin)
+                    v = *(const u32x4*)(xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T));
+                *(u32x4*)(lds_h + pix * PIXB + part * 16) = v;
+            }
+        }
+        const char* wc = wb + (size_t)c * NTAP * COT * 64;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            if (WPK || ky == 0) {
+                if (WPK && ky > 0) __syncthreads();   // previous kernel row's weights consumed
+                const char* ws = wc + (WPK ? (size_t)ky * KW * COT * 64 : 0);
+#pragma unroll
+                for (int it = 0; it < (NPW + 255) / 256; ++it) {
+                    const int pc = it * 256 + tid;
+                    if (pc < NPW) {
+                        const u32x4 v = *(const u32x4*)(ws + (size_t)pc * 16);
+                        *(u32x4*)(lds_w + (pc >> 2) * PIXB + (pc & 3) * 16) = v;
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int tapw = WPK ? kx : ky * KW + kx;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int koff = ks * 32 + h * 16;
+                    if constexpr (std::is_same<T, float>::value) {
+                        f32x4 a[MT], bb[PT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            a[m] = *(const f32x4*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
+#pragma unroll
+                        for (int q = 0; q < PT; ++q)
+                            bb[q] = *(const f32x4*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                for (int q = 0; q < PT; ++q)
+                                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bb[q][j], acc[m][q], 0, 0, 0);
+                    } else {
+                        bf16x8 a[MT], bb[PT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            a[m] = *(const bf16x8*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
+#pragma unroll
+                        for (int q = 0; q < PT; ++q)
+                            bb[q] = *(const bf16x8*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int q = 0; q < PT; ++q)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bb[q], acc[m][q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  acc[m][q][4g+i] = D[cout = 32m + 8g + 4h + i][pixel = r]
+    const int ox = ox0 + r;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int oy = oy0 + wave * PT + q;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        const size_t opix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + (size_t)ox * p.os + p.ob;
+        T* yp = (T*)p.y + opix * p.yCs + p.ycoff;
+        const T* r1p = p.r1 ? (const T*)p.r1 + opix * p.r1Cs + p.r1coff : nullptr;
+        const T* r2p = p.r2 ? (const T*)p.r2 + opix * p.r2Cs + p.r2coff : nullptr;
+        const T* mzp = p.mz ? (const T*)p.mz + opix * p.mzCs + p.mzcoff : nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = ct * COT + m * 32 + 8 * g + 4 * h;
+                if (co0 >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[m][q][4 * g + i];
+                if (p.vec) {
+                    if (p.bias) { f32x4 bv = *(const f32x4*)(p.bias + co0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += bv[i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
+                    if (r1p && co0 < p.r1cend) { float rv[4]; load4<T>(r1p + co0, rv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += p.beta1 * rv[i]; }
+                    if (r2p && co0 < p.r2cend) { float rv[4]; load4<T>(r2p + co0, rv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += p.beta2 * rv[i]; }
+                    if (p.act) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
+                    if (mzp && co0 >= p.mzc0) { float zv[4]; load4<T>(mzp + co0, zv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] *= (zv[i] > 0.f ? 1.f : p.mslope); }
+                    store4<T>(yp + co0, v);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + i;
+                        if (co >= p.Cout) continue;
+                        float u = v[i];
+                        if (p.bias) u += p.bias[co];
+                        u *= p.alpha;
+                        if (r1p && co < p.r1cend) u += p.beta1 * to_f(r1p[co]);
+                        if (r2p && co < p.r2cend) u += p.beta2 * to_f(r2p[co]);
+                        if (p.act) u = u > 0.f ? u : u * p.slope;
+                        if (mzp && co >= p.mzc0) u *= (to_f(mzp[co]) > 0.f ? 1.f : p.mslope);
+                        yp[co] = from_f<T>(u);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host launcher
+template <typename T, int KH, int KW, int S, int MT, int PT, bool WPK>
+static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
+    constexpr int TH = 4 * PT, TW = 32;
+    constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
+    constexpr int COT = 32 * MT, NTAP = KH * KW;
+    constexpr size_t SMEM = (size_t)IHT * IWT * 80 + (size_t)(WPK ? KW : NTAP) * COT * 80;
+    static bool attr_set = false;
+    auto kern = conv_igemm_k<T, KH, KW, S, MT, PT, WPK>;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set = true;
+    }
+    ConvP q = p;
+    q.tiles_x = cdiv(p.OW, TW);
+    q.tiles_y = cdiv(p.OH, TH);
+    dim3 grid((unsigned)((size_t)q.tiles_x * q.tiles_y * p.B), (unsigned)ctiles, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, q);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int MT>
+static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hipStream_t st) {
+#define SG_CASE(KH_, KW_, S_, PT_, WPK_) \
+    if (kh == KH_ && kw == KW_ && s == S_) return launch_igemm<T, KH_, KW_, S_, MT, PT_, WPK_>(p, ctiles, st);
+    SG_CASE(3, 3, 1, 2, false)
+    SG_CASE(1, 1, 1, 2, false)
+    SG_CASE(2, 2, 2, 1, false)
+    SG_CASE(2, 2, 1, 2, false)
+    SG_CASE(1, 2, 1, 2, false)
+    SG_CASE(2, 1, 1, 2, false)
+    SG_CASE(4, 4, 2, 1, true)
+    SG_CASE(4, 4, 1, 2, true)
+    SG_CASE(3, 3, 2, 1, false)
+#undef SG_CASE
+    SG_FAIL("srcgan_conv_igemm: unsupported kernel %dx%d stride %d", kh, kw, s);
+}
+
+extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
+    SG_REQUIRE(d && d->x && d->wp && d->y, "srcgan_conv_igemm: null pointer");
+    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_igemm: bad dtype %d", d->dtype);
+    const int esz = d->dtype == SRCGAN_F32 ? 4 : 2;
+    const int epp = 16 / esz;
+    SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0,
+               "srcgan_conv_igemm: non-positive dimension");
+    SG_REQUIRE(d->Cin % epp == 0 && d->x_cs % epp == 0 && d->x_coff % epp == 0,
+               "srcgan_conv_igemm: input channels/stride/offset (%d,%d,%d) must be multiples of %d", d->Cin, d->x_cs, d->x_coff, epp);
+    SG_REQUIRE(d->x_coff + d->Cin <= d->x_cs && d->y_coff + d->Cout <= d->y_cs, "srcgan_conv_igemm: channel slice exceeds stride");
+    SG_REQUIRE(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->wp % 16) == 0, "srcgan_conv_igemm: x/wp must be 16-byte aligned");
+    SG_REQUIRE(d->os >= 1 && d->oa >= 0 && d->ob >= 0 && d->oa < d->os && d->ob < d->os, "srcgan_conv_igemm: bad output scale/offset");
+    SG_REQUIRE((d->OH - 1) * d->os + d->oa < d->YH && (d->OW - 1) * d->os + d->ob < d->YW, "srcgan_conv_igemm: output extent exceeds tensor");
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.x = d->x; p.wp = d->wp; p.bias = d->bias; p.y = d->y; p.r1 = d->r1; p.r2 = d->r2; p.mz = d->mz;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xCs = d->x_cs; p.xcoff = d->x_coff;
+    p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.YH = d->YH; p.YW = d->YW; p.yCs = d->y_cs; p.ycoff = d->y_coff;
+    p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.os = d->os; p.oa = d->oa; p.ob = d->ob;
+    p.r1Cs = d->r1_cs; p.r1coff = d->r1_coff; p.r1cend = d->r1_cend;
+    p.r2Cs = d->r2_cs; p.r2coff = d->r2_coff; p.r2cend = d->r2_cend;
+    p.mzCs = d->mz_cs; p.mzcoff = d->mz_coff; p.mzc0 = d->mz_c0;
+    p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
+    p.act = d->act;
+    const int kce = 64 / esz;
+    p.nchunk = cdiv(d->Cin, kce);
+    auto m4 = [](int v) { return (v & 3) == 0; };
+    p.vec = m4(d->Cout) && m4(d->y_cs) && m4(d->y_coff) && ((uintptr_t)d->y % 16 == 0) &&
+            (!d->bias || ((uintptr_t)d->bias % 16 == 0)) &&
+            (!d->r1 || (m4(d->r1_cs) && m4(d->r1_coff) && m4(d->r1_cend) && (uintptr_t)d->r1 % 16 == 0)) &&
+            (!d->r2 || (m4(d->r2_cs) && m4(d->r2_coff) && m4(d->r2_cend) && (uintptr_t)d->r2 % 16 == 0)) &&
+            (!d->mz || (m4(d->mz_cs) && m4(d->mz_coff) && m4(d->mz_c0) && (uintptr_t)d->mz % 16 == 0));
+    hipStream_t st = (hipStream_t)stream;
+    // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
+    if (d->Cout <= 32) {
+        if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);
+        return dispatch_shape<__bf16, 1>(p, d->kh, d->kw, d->stride, 1, st);
+    }
+    const int ctiles = cdiv(d->Cout, 64);
+    if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
+    return dispatch_shape<__bf16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
+}

@@ -1,0 +1,302 @@
+// Weight-gradient kernel for gfx950: dW[co][tap][ci] = sum_pixels dy[p][co] * x[p*s + tap - pad][ci].
+// GEMM with K = pixels (millions), M = Cout tile, N = 32 input channels, per filter tap.
+// Replaces the wgrad third of aten::convolution_backward behind reference
+// src/model/rddb.py:52-58 (RDB convs), rddb.py:28-38 (deconv), model/model.py:612-634 (PatchGAN).
+//
+// Decomposition: grid = (Cin/32 tiles, Cout tiles, nsplit pixel ranges).  A workgroup walks its
+// range of 8x32 (or 4x32) output-pixel tiles; per tile it stages the dy tile and the x halo tile
+// (NHWC, 32-channel planes, *unpadded* 64 B / 128 B pixels) in LDS; its waves split the filter taps and
+// keep every tap's 32x32 f32 accumulator in registers across the whole range (split-K in registers,
+// no atomics).  Partial results go to an f32 slab; a second kernel reduces the nsplit slabs in a
+// fixed order (deterministic) and scatters into the canonical torch gradient layout.
+//
+// Operand fetch: K (pixels) must run along the lane's fragment, but NHWC keeps channels contiguous,
+// so bf16 fragments are read with ds_read_b64_tr_b16 (4 pixels x 16 channels transposed per 16 lanes;
+// 4 consecutive 64-B pixels = one 256-B bank row -> conflict free).  f32 uses plain ds_read_b32
+// (mfma_32x32x2_f32 takes one element per lane).
+#include "common.h"
+#include <type_traits>
+
+struct WgradP {
+    const void* dy; const void* x; float* slab;
+    int B, H, W, Cin, xCs, xcoff;
+    int OH, OW, Cout, dyCs, dycoff;
+    int pad_y, pad_x;
+    int nsplit, tiles_x, tiles_y, ntiles, citiles, ctiles;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+    // two transposed 4x16 reads -> 8 consecutive-k bf16 for this lane's row/column
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int KH, int KW, int S, int MT, int TH, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
+    using D = DT<T>;
+    constexpr int TW = 32, NTAP = KH * KW, COT = 32 * MT;
+    constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
+    constexpr int PB = 32 * (int)sizeof(T);          // bytes per pixel per 32-channel plane
+    constexpr int PPP = PB / 16;                     // 16-byte pieces per pixel
+    constexpr int TPW = (NTAP + NW - 1) / NW;        // taps per wave
+    constexpr int NT = NW * 64;
+    constexpr int NPD = MT * TH * TW * PPP;          // pieces of the dy tile
+    constexpr int NPX = IHT * IWT * PPP;             // pieces of the x halo tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_d = smem;                              // [MT][TH*TW][PB]
+    char* lds_x = smem + MT * TH * TW * PB;          // [IHT*IWT][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int cit = blockIdx.x, ct = blockIdx.y, split = blockIdx.z;
+
+    f32x16 acc[TPW][MT];
+#pragma unroll
+    for (int a = 0; a < TPW; ++a)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][m][i] = 0.f;
+
+    const int t_begin = (int)((long)p.ntiles * split / p.nsplit);
+    const int t_end = (int)((long)p.ntiles * (split + 1) / p.nsplit);
+    for (int t = t_begin; t < t_end; ++t) {
+        int q = t;
+        const int tx = q % p.tiles_x; q /= p.tiles_x;
+        const int ty = q % p.tiles_y;
+        const int b = q / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int gy0 = oy0 * S - p.pad_y, gx0 = ox0 * S - p.pad_x;
+        const char* dyb = (const char*)p.dy + ((size_t)b * p.OH * p.OW * p.dyCs + p.dycoff) * sizeof(T);
+        const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+        __syncthreads();
+        // ---- dy tile: plane m holds channels [ct*COT + 32m, +32)
+#pragma unroll
+        for (int it = 0; it < (NPD + NT - 1) / NT; ++it) {
+            const int pc = it * NT + tid;
+            if (pc < NPD) {
+                const int part = pc % PPP;
+                const int pix = (pc / PPP) % (TH * TW);
+                const int m = pc / (PPP * TH * TW);
+                const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+                const int ch = ct * COT + m * 32 + part * D::EPP;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (oy < p.OH && ox < p.OW && ch < p.Cout)
+                    v = *(const u32x4*)(dyb + ((size_t)(oy * p.OW + ox) * p.dyCs + ch) * sizeof(T));
+                *(u32x4*)(lds_d + (m * TH * TW + pix) * PB + part * 16) = v;
+            }
+        }
+        // ---- x halo tile: channels [cit*32, +32)
+#pragma unroll
+        for (int it = 0; it < (NPX + NT - 1) / NT; ++it) {
+            const int pc = it * NT + tid;
+            if (pc < NPX) {
+                const int part = pc % PPP;
+                const int pix = pc / PPP;
+                const int iy = pix / IWT, ix = pix - iy * IWT;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                const int ch = cit * 32 + part * D::EPP;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.Cin)
+                    v = *(const u32x4*)(xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T));
+                *(u32x4*)(lds_x + pix * PB + part * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (std::is_same<T, float>::value) {
+            // mfma_32x32x2_f32: lane (r,h) supplies A[row r][k = h], B[k = h][col r]; one MFMA eats 2 pixels.
+#pragma unroll 4
+            for (int kk = 0; kk < TH * TW / 2; ++kk) {
+                const int pix = 2 * kk + h;
+                const int py = pix / TW, px = pix % TW;
+                float a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *(const float*)(lds_d + (m * TH * TW + pix) * PB + r * 4);
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) {
+                    const int tap = wave + tl * NW;
+                    if (tap < NTAP) {
+                        const int ky = tap / KW, kx = tap % KW;
+                        const float bv = *(const float*)(lds_x + ((py * S + ky) * IWT + px * S + kx) * PB + r * 4);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[tl][m], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // mfma_32x32x16_bf16: lane (r,h) needs k = 8h..8h+7 (pixels) for its channel r.
+            // transposed read geometry: 16-lane group gq: channels 16*(gq&1)+i, lane 4q+pp supplies
+            // the address of pixel row q, channels 4pp..4pp+3 of the group's 16.
+            const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
+            const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
+#pragma unroll 2
+            for (int kk = 0; kk < TH * 2; ++kk) {
+                const int py = kk >> 1, xh = (kk & 1) * 16;
+                const int px0 = xh + 8 * h + qq;           // first of this lane's two address pixels
+                bf16x8 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const char* base = lds_d + (m * TH * TW + py * TW + px0) * PB + choff;
+                    a[m] = tr_frag(base, base + 4 * PB);
+                }
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) {
+                    const int tap = wave + tl * NW;
+                    if (tap < NTAP) {
+                        const int ky = tap / KW, kx = tap % KW;
+                        const char* base = lds_x + ((py * S + ky) * IWT + px0 * S + kx) * PB + choff;
+                        const bf16x8 bv = tr_frag(base, base + 4 * S * PB);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[tl][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- partial slab: [split][ct][cit][tap][co (COT)][ci (32)];  acc[.][m][4g+i] = D[co = 32m+8g+4h+i][ci = r]
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        const int tap = wave + tl * NW;
+        if (tap >= NTAP) continue;
+        float* sp = p.slab + ((((size_t)split * p.ctiles + ct) * p.citiles + cit) * NTAP + tap) * (COT * 32);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = m * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                sp[co * 32 + r] = acc[tl][m][i];
+            }
+    }
+}
+
+struct WredP {
+    const float* slab; float* grad;
+    int nsplit, ctiles, citiles, ntap, kw, COT, Cout, Cin;
+    long sr, sk, sty, stx, off;
+    float alpha; int accumulate;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const WredP p) {
+    const long total = (long)p.ctiles * p.citiles * p.ntap * p.COT * 32;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        long q = e;
+        const int ci_l = (int)(q % 32); q /= 32;
+        const int co_l = (int)(q % p.COT); q /= p.COT;
+        const int tap = (int)(q % p.ntap); q /= p.ntap;
+        const int cit = (int)(q % p.citiles);
+        const int ct = (int)(q / p.citiles);
+        const int co = ct * p.COT + co_l, ci = cit * 32 + ci_l;
+        if (co >= p.Cout || ci >= p.Cin) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) s += p.slab[(size_t)sp * total + e];
+        const int ky = tap / p.kw, kx = tap % p.kw;
+        float* g = p.grad + p.off + co * p.sr + ci * p.sk + ky * p.sty + kx * p.stx;
+        const float v = s * p.alpha;
+        *g = p.accumulate ? (*g + v) : v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static inline int wg_cot(int Cout) { return Cout <= 32 ? 32 : 64; }
+
+extern "C" size_t srcgan_conv_wgrad_slab_bytes(int Cout, int Cin, int kh, int kw, int nsplit) {
+    const int cot = wg_cot(Cout);
+    return (size_t)nsplit * cdiv(Cout, cot) * cdiv(Cin, 32) * kh * kw * cot * 32 * sizeof(float);
+}
+
+extern "C" int srcgan_conv_wgrad_nsplit(int B, int OH, int OW, int Cout, int Cin, int stride) {
+    const int th = stride == 2 ? 4 : 8;
+    const long ntiles = (long)B * cdiv(OH, th) * cdiv(OW, 32);
+    const long pairs = (long)cdiv(Cout, wg_cot(Cout)) * cdiv(Cin, 32);
+    long want = cdivl(1024, pairs);          // ~4 workgroups per CU over the chip
+    if (want > ntiles) want = ntiles;
+    if (want > 256) want = 256;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+template <typename T, int KH, int KW, int S, int MT, int TH, int NW>
+static int launch_wgrad(WgradP p, hipStream_t st) {
+    constexpr int TW = 32, PB = 32 * (int)sizeof(T);
+    constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
+    constexpr size_t SMEM = (size_t)MT * TH * TW * PB + (size_t)IHT * IWT * PB;
+    static_assert(SMEM <= 160 * 1024, "wgrad tile exceeds LDS");
+    auto kern = conv_wgrad_k<T, KH, KW, S, MT, TH, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set = true;
+    }
+    p.tiles_x = cdiv(p.OW, TW);
+    p.tiles_y = cdiv(p.OH, TH);
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
+    dim3 grid((unsigned)p.citiles, (unsigned)p.ctiles, (unsigned)p.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), SMEM, st, p);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int MT>
+static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st) {
+#define SG_CASE(KH_, KW_, S_, TH_, NW_) \
+    if (kh == KH_ && kw == KW_ && s == S_) return launch_wgrad<T, KH_, KW_, S_, MT, TH_, NW_>(p, st);
+    SG_CASE(3, 3, 1, 8, 3)
+    SG_CASE(2, 2, 2, 4, 4)
+    SG_CASE(4, 4, 2, 4, 4)
+    SG_CASE(4, 4, 1, 8, 4)
+    SG_CASE(3, 3, 2, 4, 3)
+#undef SG_CASE
+    SG_FAIL("srcgan_conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, s);
+}
+
+extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
+    SG_REQUIRE(d && d->dy && d->x && d->slab && d->grad, "srcgan_conv_wgrad: null pointer");
+    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_wgrad: bad dtype %d", d->dtype);
+    const int esz = d->dtype == SRCGAN_F32 ? 4 : 2, epp = 16 / esz;
+    SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0 && d->nsplit > 0,
+               "srcgan_conv_wgrad: non-positive dimension");
+    SG_REQUIRE(d->x_cs % epp == 0 && d->x_coff % epp == 0 && d->dy_cs % epp == 0 && d->dy_coff % epp == 0,
+               "srcgan_conv_wgrad: channel strides/offsets must be multiples of %d", epp);
+    SG_REQUIRE(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "srcgan_conv_wgrad: tensors must be 16-byte aligned");
+    // channels are fetched in 16-byte pieces: round the read extents up, the tensors must own (zero) padding
+    const int cin_r = cdiv(d->Cin, epp) * epp, cout_r = cdiv(d->Cout, epp) * epp;
+    SG_REQUIRE(d->x_coff + cin_r <= d->x_cs && d->dy_coff + cout_r <= d->dy_cs,
+               "srcgan_conv_wgrad: channel slice (rounded to %d) exceeds stride", epp);
+    WgradP p;
+    memset(&p, 0, sizeof(p));
+    p.dy = d->dy; p.x = d->x; p.slab = d->slab;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = cin_r; p.xCs = d->x_cs; p.xcoff = d->x_coff;
+    p.OH = d->OH; p.OW = d->OW; p.Cout = cout_r; p.dyCs = d->dy_cs; p.dycoff = d->dy_coff;
+    p.pad_y = d->pad_y; p.pad_x = d->pad_x;
+    const int cot = wg_cot(d->Cout);
+    p.ctiles = cdiv(d->Cout, cot); p.citiles = cdiv(d->Cin, 32);
+    const int th = d->stride == 2 ? 4 : 8;
+    const long ntiles = (long)d->B * cdiv(d->OH, th) * cdiv(d->OW, 32);
+    p.nsplit = d->nsplit > ntiles ? (int)ntiles : d->nsplit;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (cot == 32) rc = d->dtype == SRCGAN_F32 ? dispatch_wgrad<float, 1>(p, d->kh, d->kw, d->stride, st)
+                                               : dispatch_wgrad<__bf16, 1>(p, d->kh, d->kw, d->stride, st);
+    else rc = d->dtype == SRCGAN_F32 ? dispatch_wgrad<float, 2>(p, d->kh, d->kw, d->stride, st)
+                                     : dispatch_wgrad<__bf16, 2>(p, d->kh, d->kw, d->stride, st);
+    if (rc) return rc;
+    WredP q;
+    q.slab = d->slab; q.grad = d->grad; q.nsplit = p.nsplit; q.ctiles = p.ctiles; q.citiles = p.citiles;
+    q.ntap = d->kh * d->kw; q.kw = d->kw; q.COT = cot; q.Cout = d->Cout; q.Cin = d->Cin;
+    q.sr = d->sr; q.sk = d->sk; q.sty = d->sty; q.stx = d->stx; q.off = d->off;
+    q.alpha = d->alpha; q.accumulate = d->accumulate;
+    const long total = (long)p.ctiles * p.citiles * q.ntap * cot * 32;
+    int blocks = (int)(cdivl(total, 256) > 2048 ? 2048 : cdivl(total, 256));
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(blocks), dim3(256), 0, st, q);
+    SG_LAUNCH_CHECK();
+    return 0;
+}

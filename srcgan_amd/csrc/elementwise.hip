@@ -1,0 +1,489 @@
+// Bandwidth-bound kernels of the SRCGAN hot path (gfx950): layout changes, weight packing,
+// per-channel reductions (bias grad, BatchNorm statistics), BatchNorm+LeakyReLU apply / backward,
+// residual-gradient joins, L1 / MSE / lsgan loss reductions and the in-step preprocessing.
+// All reductions are two-stage and order-fixed (deterministic); wavefront (64-lane) shuffles do
+// the in-wave part.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void srcgan_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* srcgan_last_error(void) { return g_err; }
+extern "C" int srcgan_version(void) { return 100; }
+extern "C" int srcgan_dtype_size(int dtype) { return dtype == SRCGAN_F32 ? 4 : (dtype == SRCGAN_BF16 ? 2 : 0); }
+
+#define DISPATCH_DTYPE(dtype, ...) \
+    if ((dtype) == SRCGAN_F32) { using T = float; __VA_ARGS__; } \
+    else if ((dtype) == SRCGAN_BF16) { using T = __bf16; __VA_ARGS__; } \
+    else SG_FAIL("bad dtype %d", (int)(dtype));
+
+static inline int ew_blocks(long n, int per_block = 256) {
+    long b = cdivl(n, per_block);
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// --------------------------------------------------------------------------- layout
+// NCHW f32 -> NHWC T.  A block transposes a [C][64 pixels] panel through LDS so both sides coalesce.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ src, T* __restrict__ dst,
+                                                      int C, long HW, int cs, long npanels) {
+    __shared__ float tile[64 * 33];
+    for (long pn = blockIdx.x; pn < npanels; pn += gridDim.x) {
+        const long panels_per_img = (HW + 63) / 64;
+        const long b = pn / panels_per_img, p0 = (pn % panels_per_img) * 64;
+        for (int c0 = 0; c0 < cs; c0 += 32) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+                const int c = c0 + e / 64, px = e % 64;
+                float v = 0.f;
+                if (c < C && p0 + px < HW) v = src[((size_t)b * C + c) * HW + p0 + px];
+                tile[px * 33 + e / 64] = v;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+                const int px = e / 32, cl = e % 32;
+                if (c0 + cl < cs && p0 + px < HW)
+                    dst[((size_t)b * HW + p0 + px) * cs + c0 + cl] = from_f<T>(tile[px * 33 + cl]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src, float* __restrict__ dst,
+                                                      int C, long HW, int cs, int coff, long npanels) {
+    __shared__ float tile[64 * 33];
+    for (long pn = blockIdx.x; pn < npanels; pn += gridDim.x) {
+        const long panels_per_img = (HW + 63) / 64;
+        const long b = pn / panels_per_img, p0 = (pn % panels_per_img) * 64;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+                const int px = e / 32, cl = e % 32;
+                float v = 0.f;
+                if (c0 + cl < C && p0 + px < HW) v = to_f(src[((size_t)b * HW + p0 + px) * cs + coff + c0 + cl]);
+                tile[px * 33 + cl] = v;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+                const int c = c0 + e / 64, px = e % 64;
+                if (c < C && p0 + px < HW) dst[((size_t)b * C + c) * HW + p0 + px] = tile[px * 33 + e / 64];
+            }
+        }
+    }
+}
+
+extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cs, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "srcgan_nchw_f32_to_nhwc: bad arguments");
+    const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_nhwc_k<T>, dim3(ew_blocks(np, 1)), dim3(256), 0, (hipStream_t)stream,
+                                             src, (T*)dst, C, HW, cs, np));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int cs, int coff, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C + coff, "srcgan_nhwc_to_nchw_f32: bad arguments");
+    const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nhwc_to_nchw_k<T>, dim3(ew_blocks(np, 1)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)src, dst, C, HW, cs, coff, np));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- weight packing
+// Wp[rt][chunk][tap][row (COT)][k (KCE)], zero padded.  COT = rows<=32 ? 32 : 64 (must match conv_igemm).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_k(const float* __restrict__ w, T* __restrict__ wp, int rows, int kdim,
+                                                     int tys, int txs, long sr, long sk, long sty, long stx, long off,
+                                                     int cot, int nchunk, long total) {
+    constexpr int KCE = DT<T>::KCE;
+    const int ntap = tys * txs;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        long q = e;
+        const int kl = (int)(q % KCE); q /= KCE;
+        const int rl = (int)(q % cot); q /= cot;
+        const int tap = (int)(q % ntap); q /= ntap;
+        const int ch = (int)(q % nchunk);
+        const int rt = (int)(q / nchunk);
+        const int row = rt * cot + rl, k = ch * KCE + kl;
+        float v = 0.f;
+        if (row < rows && k < kdim) v = w[off + row * sr + k * sk + (tap / txs) * sty + (tap % txs) * stx];
+        wp[e] = from_f<T>(v);
+    }
+}
+
+extern "C" size_t srcgan_packed_weight_bytes(int rows, int kdim, int ntaps, int dtype) {
+    const int esz = dtype == SRCGAN_F32 ? 4 : 2, kce = 64 / esz;
+    const int cot = rows <= 32 ? 32 : 64;
+    return (size_t)cdiv(rows, cot) * cdiv(kdim, kce) * ntaps * cot * 64;
+}
+
+extern "C" int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, int tys, int txs,
+                                  long sr, long sk, long sty, long stx, long off, int dtype, void* stream) {
+    SG_REQUIRE(w && wp && rows > 0 && kdim > 0 && tys > 0 && txs > 0, "srcgan_pack_weight: bad arguments");
+    const int esz = dtype == SRCGAN_F32 ? 4 : 2, kce = 64 / esz;
+    const int cot = rows <= 32 ? 32 : 64, nchunk = cdiv(kdim, kce);
+    const long total = (long)cdiv(rows, cot) * nchunk * tys * txs * cot * kce;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weight_k<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                                             w, (T*)wp, rows, kdim, tys, txs, sr, sk, sty, stx, off, cot, nchunk, total));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- column reductions
+// Block = 64 channel lanes x 4 pixel lanes.  Stage 1 writes partial[which][blk][c]; stage 2 sums
+// the blocks in index order.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_k(const T* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
+                                                    int zCs, int zcoff, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, long npix, int C,
+                                                    float* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const long per = cdivl(npix, gridDim.x);
+    const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cx;
+        float s0 = 0.f, s1 = 0.f;
+        if (c < C) {
+            const float mu = (MODE >= 1) ? mean[c] : 0.f;
+            const float rs = (MODE == 2) ? rstd[c] : 0.f;
+            for (long px = p0 + py; px < p1; px += 4) {
+                const float v = to_f(a[(size_t)px * aCs + acoff + c]);
+                if (MODE == 0) s0 += v;
+                else if (MODE == 1) { const float dv = v - mu; s0 += dv * dv; }
+                else { const float zz = to_f(z[(size_t)px * zCs + zcoff + c]); s0 += v; s1 += v * (zz - mu) * rs; }
+            }
+        }
+        red[0][py][cx] = s0; red[1][py][cx] = s1;
+        __syncthreads();
+        if (py == 0 && c < C) {
+            partial[(size_t)blockIdx.x * C + c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+            if (MODE == 2)
+                partial[((size_t)gridDim.x + blockIdx.x) * C + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ partial, int nblk, int C, float scale,
+                                                      float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += partial[(size_t)b * C + c];
+        if (out1) s1 += partial[((size_t)nblk + b) * C + c];
+    }
+    out0[c] = s0 * scale;
+    if (out1) out1[c] = s1 * scale;
+}
+
+extern "C" int srcgan_col_reduce_blocks(long npix) {
+    long b = cdivl(npix, 256);
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, const void* z, int z_cs, int z_coff,
+                                 const float* m, const float* rstd, long npix, int C, float scale,
+                                 float* out0, float* out1, float* scratch, int dtype, void* stream) {
+    SG_REQUIRE(a && out0 && scratch && npix > 0 && C > 0, "srcgan_col_reduce: bad arguments");
+    SG_REQUIRE(mode >= 0 && mode <= 2, "srcgan_col_reduce: bad mode %d", mode);
+    SG_REQUIRE(mode == 0 || m, "srcgan_col_reduce: mode %d needs mean", mode);
+    SG_REQUIRE(mode != 2 || (z && rstd && out1), "srcgan_col_reduce: mode 2 needs z, rstd, out1");
+    const int nblk = srcgan_col_reduce_blocks(npix);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        if (mode == 0) hipLaunchKernelGGL((col_reduce_k<T, 0>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+        else if (mode == 1) hipLaunchKernelGGL((col_reduce_k<T, 1>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+        else hipLaunchKernelGGL((col_reduce_k<T, 2>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+    });
+    SG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- BatchNorm + LeakyReLU
+__global__ void bn_finalize_k(const float* mean, const float* var, float* rstd, float* rmean, float* rvar,
+                              int64_t* nbt, int C, float unbias, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    rstd[c] = rsqrtf(var[c] + eps);
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var[c] * unbias;
+}
+
+extern "C" int srcgan_bn_finalize(const float* mean, const float* var, float* rstd, float* running_mean, float* running_var,
+                                  int64_t* nbt, int C, long count, float momentum, float eps, void* stream) {
+    SG_REQUIRE(mean && var && rstd && C > 0 && count > 0, "srcgan_bn_finalize: bad arguments");
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var, rstd,
+                       running_mean, running_var, nbt, C, unbias, momentum, eps);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_eval_rstd_k(const float* rvar, float* rstd, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) rstd[c] = rsqrtf(rvar[c] + eps);
+}
+extern "C" int srcgan_bn_eval_rstd(const float* running_var, float* rstd, int C, float eps, void* stream) {
+    SG_REQUIRE(running_var && rstd && C > 0, "srcgan_bn_eval_rstd: bad arguments");
+    hipLaunchKernelGGL(bn_eval_rstd_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_var, rstd, C, eps);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ z, T* __restrict__ y, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, long n4, int C, int cs, float slope) {
+    // cs == C required (dense NHWC), C % 4 == 0
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const int c = (int)((e * 4) % cs);
+        float v[4];
+        load4<T>(z + e * 4, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float u = (v[i] - mean[c + i]) * rstd[c + i] * gamma[c + i] + beta[c + i];
+            v[i] = u > 0.f ? u : u * slope;
+        }
+        store4<T>(y + e * 4, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* __restrict__ g, const T* __restrict__ z, T* __restrict__ dz,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                                      const float* __restrict__ sum_gx, long n4, int cs, float invn) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const int c = (int)((e * 4) % cs);
+        float gv[4], zv[4];
+        load4<T>(g + e * 4, gv);
+        load4<T>(z + e * 4, zv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (zv[i] - mean[c + i]) * rstd[c + i];
+            gv[i] = gamma[c + i] * rstd[c + i] * (gv[i] - sum_g[c + i] * invn - xh * sum_gx[c + i] * invn);
+        }
+        store4<T>(dz + e * 4, gv);
+    }
+}
+
+
+extern "C" int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, long npix, int C, int cs, float slope, int dtype, void* stream) {
+    SG_REQUIRE(z && y && mean && rstd && gamma && beta && npix > 0, "srcgan_bn_apply_lrelu: bad arguments");
+    SG_REQUIRE(cs == C && C % 4 == 0, "srcgan_bn_apply_lrelu: needs a dense NHWC tensor with C %% 4 == 0 (C=%d cs=%d)", C, cs);
+    const long n4 = npix * C / 4;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)z, (T*)y, mean, rstd, gamma, beta, n4, C, cs, slope));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mean, const float* rstd,
+                                   const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
+                                   int dtype, void* stream) {
+    SG_REQUIRE(g && z && dz && mean && rstd && gamma && sum_g && sum_gx && npix > 0, "srcgan_bn_bwd_apply: bad arguments");
+    SG_REQUIRE(cs == C && C % 4 == 0, "srcgan_bn_bwd_apply: needs a dense NHWC tensor with C %% 4 == 0");
+    const long n4 = npix * C / 4;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)g, (const T*)z, (T*)dz, mean, rstd, gamma, sum_g, sum_gx, n4, cs,
+                                             1.f / (float)npix));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- residual-gradient join
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_k(T* __restrict__ y, int yCs, int ycoff, const T* __restrict__ x, int xCs,
+                                                     int xcoff, const T* __restrict__ mz, int mzCs, int mzcoff, float mslope,
+                                                     long npix, int C4) {
+    const long total = npix * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long px = e / C4; const int c = (int)(e % C4) * 4;
+        float a[4], b[4];
+        load4<T>(y + (size_t)px * yCs + ycoff + c, a);
+        load4<T>(x + (size_t)px * xCs + xcoff + c, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] += b[i];
+        if (mz) {
+            float z[4];
+            load4<T>(mz + (size_t)px * mzCs + mzcoff + c, z);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] *= (z[i] > 0.f ? 1.f : mslope);
+        }
+        store4<T>(y + (size_t)px * yCs + ycoff + c, a);
+    }
+}
+
+extern "C" int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
+                                  const void* mz, int mz_cs, int mz_coff, float mslope, long npix, int C, int dtype, void* stream) {
+    SG_REQUIRE(y && x && npix > 0 && C > 0, "srcgan_add_inplace: bad arguments");
+    SG_REQUIRE(C % 4 == 0 && y_cs % 4 == 0 && y_coff % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 &&
+               (!mz || (mz_cs % 4 == 0 && mz_coff % 4 == 0)),
+               "srcgan_add_inplace: channel counts/strides/offsets must be multiples of 4");
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_inplace_k<T>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                                             (T*)y, y_cs, y_coff, (const T*)x, x_cs, x_coff, (const T*)mz, mz_cs, mz_coff, mslope,
+                                             npix, C / 4));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- losses
+#define LOSS_BLOCKS 1024
+extern "C" int srcgan_loss_scratch_floats(void) { return LOSS_BLOCKS; }
+
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ a, const float* __restrict__ b, float label,
+                                                  long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const f32x4 av = *(const f32x4*)(a + e * 4);
+        f32x4 bv = {label, label, label, label};
+        if (KIND != 2) bv = *(const f32x4*)(b + e * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = av[i] - bv[i]; s += (KIND == 0) ? fabsf(d) : d * d; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // tail
+        const long e = n4 * 4 + threadIdx.x;
+        const float d = a[e] - (KIND == 2 ? label : b[e]);
+        s += (KIND == 0) ? fabsf(d) : d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_final_k(const float* __restrict__ partial, int nblk, float invn, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) * invn;
+}
+
+extern "C" int srcgan_loss_fwd(int kind, const float* a, const float* b, float label, long n, float* out, float* scratch, void* stream) {
+    SG_REQUIRE(a && out && scratch && n > 0 && kind >= 0 && kind <= 2, "srcgan_loss_fwd: bad arguments");
+    SG_REQUIRE(kind == 2 || b, "srcgan_loss_fwd: kind %d needs b", kind);
+    SG_REQUIRE(((uintptr_t)a % 16) == 0 && (kind == 2 || ((uintptr_t)b % 16) == 0), "srcgan_loss_fwd: inputs must be 16-byte aligned");
+    long nb = cdivl(n / 4 + 1, 256); if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(loss_fwd_k<0>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    else if (kind == 1) hipLaunchKernelGGL(loss_fwd_k<1>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    else hipLaunchKernelGGL(loss_fwd_k<2>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    SG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(256), 0, st, scratch, (int)nb, (float)(1.0 / (double)n), out);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ a, const float* __restrict__ b, float label, long n,
+                                                  const float* __restrict__ gout, float gscale, float* __restrict__ da) {
+    const float g = gout[0] * gscale;     // upstream gradient * 1/n
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float d = a[e] - (KIND == 2 ? label : b[e]);
+        if (KIND == 0) da[e] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+        else da[e] = 2.f * d * g;
+    }
+}
+
+extern "C" int srcgan_loss_bwd(int kind, const float* a, const float* b, float label, long n, const float* gout,
+                               float gscale, float* da, void* stream) {
+    SG_REQUIRE(a && gout && da && n > 0 && kind >= 0 && kind <= 2, "srcgan_loss_bwd: bad arguments");
+    SG_REQUIRE(kind == 2 || b, "srcgan_loss_bwd: kind %d needs b", kind);
+    hipStream_t st = (hipStream_t)stream;
+    const float gs = gscale / (float)n;
+    if (kind == 0) hipLaunchKernelGGL(loss_bwd_k<0>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    else if (kind == 1) hipLaunchKernelGGL(loss_bwd_k<1>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    else hipLaunchKernelGGL(loss_bwd_k<2>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void psnr_k(const float* mse, float* out) { *out = 10.f * log10f(1.f / *mse); }
+extern "C" int srcgan_psnr_from_mse(const float* mse, float* out, void* stream) {
+    SG_REQUIRE(mse && out, "srcgan_psnr_from_mse: null pointer");
+    hipLaunchKernelGGL(psnr_k, dim3(1), dim3(1), 0, (hipStream_t)stream, mse, out);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- preprocessing
+__global__ __launch_bounds__(256) void rgb_to_gray_k(const float* __restrict__ rgb, float* __restrict__ gray, long HW, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / HW, p = e % HW;
+        const float* s = rgb + (size_t)b * 3 * HW + p;
+        // same association as the reference expression (trainCas.py:85-87)
+        gray[e] = (0.2125f * s[0] + 0.7154f * s[HW]) + 0.0721f * s[2 * HW];
+    }
+}
+extern "C" int srcgan_rgb_to_gray(const float* rgb, float* gray, int B, int H, int W, void* stream) {
+    SG_REQUIRE(rgb && gray && B > 0 && H > 0 && W > 0, "srcgan_rgb_to_gray: bad arguments");
+    const long HW = (long)H * W, total = HW * B;
+    hipLaunchKernelGGL(rgb_to_gray_k, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, rgb, gray, HW, total);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// bilinear, align_corners=False, scale 1/up (up even): source coord = (o+.5)*up-.5 = o*up + up/2 - .5
+// -> mean of pixels (up/2-1, up/2) in each direction, weights exactly .5/.5.
+__global__ __launch_bounds__(256) void bilinear_down_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                       int up, long total) {
+    const int OH = H / up, OW = W / up;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % OW); const long q = e / OW;
+        const int oy = (int)(q % OH); const long bc = q / OH;
+        const float* s = src + (size_t)bc * H * W;
+        const int y0 = oy * up + up / 2 - 1, x0 = ox * up + up / 2 - 1;
+        const float top = 0.5f * s[(size_t)y0 * W + x0] + 0.5f * s[(size_t)y0 * W + x0 + 1];
+        const float bot = 0.5f * s[(size_t)(y0 + 1) * W + x0] + 0.5f * s[(size_t)(y0 + 1) * W + x0 + 1];
+        dst[e] = 0.5f * top + 0.5f * bot;
+    }
+}
+extern "C" int srcgan_bilinear_down(const float* src, float* dst, int B, int C, int H, int W, int up, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "srcgan_bilinear_down: bad arguments");
+    SG_REQUIRE(up >= 2 && up % 2 == 0 && H % up == 0 && W % up == 0, "srcgan_bilinear_down: up must be even and divide H, W");
+    const long total = (long)B * C * (H / up) * (W / up);
+    hipLaunchKernelGGL(bilinear_down_k, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, up, total);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// nearest resize, torch 'nearest' rule: src = floor(dst * in/out)
+__global__ __launch_bounds__(256) void nearest_resize_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                        int OH, int OW, long total) {
+    const float sy = (float)H / OH, sx = (float)W / OW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % OW); const long q = e / OW;
+        const int oy = (int)(q % OH); const long bc = q / OH;
+        int iy = (int)floorf(oy * sy), ix = (int)floorf(ox * sx);
+        iy = iy < H - 1 ? iy : H - 1; ix = ix < W - 1 ? ix : W - 1;
+        dst[e] = src[((size_t)bc * H + iy) * W + ix];
+    }
+}
+extern "C" int srcgan_nearest_resize(const float* src, float* dst, int B, int C, int H, int W, int OH, int OW, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "srcgan_nearest_resize: bad arguments");
+    const long total = (long)B * C * OH * OW;
+    hipLaunchKernelGGL(nearest_resize_k, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, total);
+    SG_LAUNCH_CHECK();
+    return 0;
+}

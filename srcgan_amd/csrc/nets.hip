@@ -1,0 +1,651 @@
+// Whole-network sequencing for the SRCGAN hot path: one C call per nn.Module.forward and one per
+// autograd backward.  Pure host code that chains the gfx950 kernels of conv_igemm.hip,
+// conv_wgrad.hip and elementwise.hip on the caller's stream (no allocation, no synchronisation:
+// graph-capturable).
+//
+//   RDDBNet            reference src/model/rddb.py:48-114
+//   NLayerDiscriminator reference src/model/model.py:595-639
+//
+// Memory design (HBM): activations live in NHWC.  Each ResidualDenseBlock_5 owns ONE dense buffer of
+// nf+4*gc channels; conv k reads the channel prefix [0, nf+(k-1)gc) and writes its own slice, so the
+// four torch.cat copies of rddb.py:64-67 (and CatBackward) never exist.  conv5's epilogue fuses
+// "x5*0.2 + x" (rddb.py:68), and for RDB3 also the RRDB residual (rddb.py:82), writing straight into
+// channels [0,nf) of the next block's dense buffer.  Backward mirrors this with a dense *gradient*
+// buffer per block that the dgrads of conv5..conv1 accumulate into in place.
+#include "common.h"
+#include <vector>
+
+namespace {
+
+struct TRef { void* p; int cs; int coff; };
+static inline TRef tref(void* p, int cs, int coff = 0) { return TRef{p, cs, coff}; }
+static inline TRef sl(TRef t, int coff) { return TRef{t.p, t.cs, t.coff + coff}; }
+static const TRef TNULL = {nullptr, 0, 0};
+
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline int img_cs(int c) { return round_up(c, 8); }     // image-like tensors: channels padded to 8
+
+struct Conv {
+    srcgan_conv_desc d;
+    Conv(int dtype, int kh, int kw, int stride) {
+        memset(&d, 0, sizeof(d));
+        d.dtype = dtype; d.kh = kh; d.kw = kw; d.stride = stride;
+        d.os = 1; d.alpha = 1.f; d.slope = 0.2f; d.mslope = 0.2f;
+    }
+    Conv& in(TRef x, int B, int H, int W, int Cin) { d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.B = B; d.H = H; d.W = W; d.Cin = Cin; return *this; }
+    Conv& w(const void* wp, const float* bias = nullptr) { d.wp = wp; d.bias = bias; return *this; }
+    Conv& out(TRef y, int OH, int OW, int Cout) { d.y = y.p; d.y_cs = y.cs; d.y_coff = y.coff; d.OH = OH; d.OW = OW; d.Cout = Cout; d.YH = OH; d.YW = OW; return *this; }
+    Conv& pad(int py, int px) { d.pad_y = py; d.pad_x = px; return *this; }
+    Conv& scatter(int os, int oa, int ob, int YH, int YW) { d.os = os; d.oa = oa; d.ob = ob; d.YH = YH; d.YW = YW; return *this; }
+    Conv& alpha(float a) { d.alpha = a; return *this; }
+    Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_cend = cend; d.beta1 = beta; return *this; }
+    Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_cend = cend; d.beta2 = beta; return *this; }
+    Conv& lrelu() { d.act = 1; return *this; }
+    Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_c0 = c0; return *this; }
+    int run(void* st) { return srcgan_conv_igemm(&d, st); }
+};
+
+// canonical weight layouts
+struct WLayout { long sr, sk, sty, stx, off; };
+// Conv2d weight [co][ci][kh][kw]: forward pack rows = co
+static inline WLayout lay_fwd(int cin, int kh, int kw) { return {(long)cin * kh * kw, (long)kh * kw, kw, 1, 0}; }
+// Conv2d dgrad for stride 1: rows = ci, k = co, taps flipped
+static inline WLayout lay_dgrad_s1(int cin, int kh, int kw) { return {(long)kh * kw, (long)cin * kh * kw, -kw, -1, (long)kh * kw - 1}; }
+
+struct Bump {   // workspace bump allocator (256-byte aligned)
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
+};
+
+static int wgrad_call(int dtype, TRef dy, int OH, int OW, int Cout, TRef x, int B, int H, int W, int Cin, int kh, int kw,
+                      int stride, int pad_y, int pad_x, WLayout lay, float alpha, float* slab, float* grad, void* st) {
+    srcgan_wgrad_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dy = dy.p; d.dy_cs = dy.cs; d.dy_coff = dy.coff; d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff;
+    d.slab = slab; d.grad = grad; d.dtype = dtype; d.kh = kh; d.kw = kw; d.stride = stride;
+    d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.OH = OH; d.OW = OW; d.Cout = Cout; d.pad_y = pad_y; d.pad_x = pad_x;
+    d.nsplit = srcgan_conv_wgrad_nsplit(B, OH, OW, Cout, Cin, stride);
+    d.sr = lay.sr; d.sk = lay.sk; d.sty = lay.sty; d.stx = lay.stx; d.off = lay.off;
+    d.alpha = alpha; d.accumulate = 0;
+    return srcgan_conv_wgrad(&d, st);
+}
+static size_t wgrad_slab(int B, int OH, int OW, int Cout, int Cin, int kh, int kw, int stride) {
+    return srcgan_conv_wgrad_slab_bytes(Cout, Cin, kh, kw, srcgan_conv_wgrad_nsplit(B, OH, OW, Cout, Cin, stride));
+}
+static int bias_grad(int dtype, TRef dy, long npix, int C, float scale, float* out, float* scratch, void* st) {
+    return srcgan_col_reduce(0, dy.p, dy.cs, dy.coff, nullptr, 0, 0, nullptr, nullptr, npix, C, scale, out, nullptr, scratch, dtype, st);
+}
+
+// ======================================================================================== RDDBNet
+struct RddbPlan {
+    int dtype, esz, nf, gc, nb, C, nst, ndn;
+    int B, H, W;           // input
+    int Ht, Wt;            // trunk resolution
+    int HO, WO;            // output resolution
+    int in_cs, out_cs;
+    int nparams;
+    size_t xin, fea0, dn[5], A, szA, T, U[6], out, wpk, total;
+    // packed weights (offsets relative to wpk): per conv
+    size_t w_first_f, w_first_d, w_trunk_f, w_trunk_d, w_last_f, w_last_d;
+    std::vector<size_t> w_rdb_f, w_rdb_d;          // [nb*15]
+    size_t w_up_f[5][4], w_up_d[5];
+    size_t w_dn_f[5], w_dn_d[5][4];
+    // parameter indices
+    int p_first_w, p_first_b, p_rdb0, p_trunk_w, p_trunk_b, p_up0, p_dn0, p_last_w;
+};
+
+static int log2i(int v) { int n = 0; while ((1 << n) < v) ++n; return n; }
+
+static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
+    SG_REQUIRE(c, "rddbnet: null cfg");
+    SG_REQUIRE(c->dtype == SRCGAN_F32 || c->dtype == SRCGAN_BF16, "rddbnet: bad dtype %d", c->dtype);
+    SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8 && c->out_ch > 0 && c->out_ch <= 8, "rddbnet: in/out channels must be in 1..8");
+    SG_REQUIRE(c->nf > 0 && c->gc > 0 && c->nf % 8 == 0 && c->gc % 8 == 0, "rddbnet: nf and gc must be multiples of 8 (nf=%d gc=%d)", c->nf, c->gc);
+    SG_REQUIRE(c->nb >= 1 && c->B > 0 && c->H > 0 && c->W > 0, "rddbnet: bad nb/B/H/W");
+    SG_REQUIRE(c->up >= 1 && (c->up & (c->up - 1)) == 0 && c->up <= 16, "rddbnet: upscale_factor must be a power of two <= 16");
+    SG_REQUIRE(c->down >= 0 && (c->down == 0 || ((c->down & (c->down - 1)) == 0 && c->down <= 16)), "rddbnet: bad down factor");
+    SG_REQUIRE(!(c->down > 1 && c->up > 1), "rddbnet: up and down are exclusive");
+    P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
+    P.nf = c->nf; P.gc = c->gc; P.nb = c->nb; P.C = c->nf + 4 * c->gc;
+    P.B = c->B; P.H = c->H; P.W = c->W;
+    P.nst = c->down > 0 ? 0 : log2i(c->up);
+    P.ndn = c->down > 1 ? log2i(c->down) : 0;
+    if (P.ndn) SG_REQUIRE(c->H % c->down == 0 && c->W % c->down == 0, "rddbnet: H, W must be divisible by the down factor");
+    P.Ht = c->H >> P.ndn; P.Wt = c->W >> P.ndn;
+    P.HO = P.Ht << P.nst; P.WO = P.Wt << P.nst;
+    P.in_cs = img_cs(c->in_ch); P.out_cs = img_cs(c->out_ch);
+    const size_t e = P.esz, B = c->B;
+    Bump b;
+    P.xin = b.take(B * c->H * c->W * P.in_cs * e);
+    P.fea0 = P.ndn ? b.take(B * c->H * c->W * c->nf * e) : 0;     // conv_first output at HR (HR->LR variant only)
+    for (int s = 0; s < P.ndn; ++s) P.dn[s] = b.take(B * (c->H >> (s + 1)) * (c->W >> (s + 1)) * c->nf * e);
+    P.szA = align_up(B * P.Ht * P.Wt * P.C * e, 256);
+    P.A = b.take(P.szA * 3 * c->nb);
+    P.T = b.take(B * P.Ht * P.Wt * c->nf * e);
+    for (int s = 0; s <= P.nst; ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    P.out = b.take(B * P.HO * P.WO * P.out_cs * e);
+    P.wpk = b.off;
+    Bump wb;
+    auto pk = [&](int rows, int k, int taps) { return wb.take(srcgan_packed_weight_bytes(rows, k, taps, c->dtype)); };
+    P.w_first_f = pk(c->nf, P.in_cs, 9); P.w_first_d = pk(c->in_ch, c->nf, 9);
+    for (int s = 0; s < P.ndn; ++s) { P.w_dn_f[s] = pk(c->nf, c->nf, 9); for (int q = 0; q < 4; ++q) P.w_dn_d[s][q] = pk(c->nf, c->nf, 4); }
+    P.w_rdb_f.resize(c->nb * 15); P.w_rdb_d.resize(c->nb * 15);
+    for (int i = 0; i < c->nb * 3; ++i)
+        for (int k = 0; k < 5; ++k) {
+            const int cin = c->nf + k * c->gc, cout = k < 4 ? c->gc : c->nf;
+            P.w_rdb_f[i * 5 + k] = pk(cout, cin, 9);
+            P.w_rdb_d[i * 5 + k] = pk(cin, cout, 9);
+        }
+    P.w_trunk_f = pk(c->nf, c->nf, 9); P.w_trunk_d = pk(c->nf, c->nf, 9);
+    for (int s = 0; s < P.nst; ++s) { for (int q = 0; q < 4; ++q) P.w_up_f[s][q] = pk(c->nf, c->nf, 1); P.w_up_d[s] = pk(c->nf, c->nf, 4); }
+    P.w_last_f = pk(c->out_ch, c->nf, 9); P.w_last_d = pk(c->nf, P.out_cs, 9);
+    P.total = align_up(P.wpk + wb.off + 256, 256);
+    // parameter indices (state_dict order)
+    int n = 0;
+    P.p_first_w = n++; P.p_first_b = n++;
+    P.p_dn0 = n; n += 2 * P.ndn;
+    P.p_rdb0 = n; n += c->nb * 30;
+    P.p_trunk_w = n++; P.p_trunk_b = n++;
+    P.p_up0 = n; n += P.nst;
+    P.p_last_w = n++;
+    P.nparams = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c) { RddbPlan P; if (rddb_plan(c, P)) return -1; return P.nparams; }
+extern "C" size_t srcgan_rddbnet_ws_bytes(const srcgan_rddbnet_cfg* c) { RddbPlan P; if (rddb_plan(c, P)) return 0; return P.total; }
+
+namespace {
+struct RddbBwdPlan {
+    size_t dout, dU[6], dT, Pg[3], szP, dfea_dn[5], dxin, slab, colscr, biasred, total;
+};
+static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBwdPlan& Q) {
+    const size_t e = P.esz, B = c->B;
+    Bump b;
+    Q.dout = b.take(B * P.HO * P.WO * P.out_cs * e);
+    for (int s = 0; s <= P.nst; ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    Q.dT = b.take(B * P.Ht * P.Wt * c->nf * e);
+    Q.szP = B * P.Ht * P.Wt * P.C * e;
+    for (int i = 0; i < 3; ++i) Q.Pg[i] = b.take(Q.szP);
+    for (int s = 0; s <= P.ndn; ++s) Q.dfea_dn[s] = b.take(B * (c->H >> s) * (c->W >> s) * c->nf * e);
+    Q.dxin = b.take(B * c->H * c->W * P.in_cs * e);
+    size_t slab = 0;
+    auto mx = [&](size_t v) { if (v > slab) slab = v; };
+    mx(wgrad_slab(c->B, c->H, c->W, c->nf, P.in_cs, 3, 3, 1));
+    for (int k = 0; k < 5; ++k) mx(wgrad_slab(c->B, P.Ht, P.Wt, k < 4 ? c->gc : c->nf, c->nf + k * c->gc, 3, 3, 1));
+    mx(wgrad_slab(c->B, P.Ht, P.Wt, c->nf, c->nf, 3, 3, 1));
+    for (int s = 0; s < P.nst; ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
+    for (int s = 0; s < P.ndn; ++s) mx(wgrad_slab(c->B, c->H >> (s + 1), c->W >> (s + 1), c->nf, c->nf, 3, 3, 2));
+    mx(wgrad_slab(c->B, P.HO, P.WO, c->out_ch, c->nf, 3, 3, 1));
+    Q.slab = b.take(slab);
+    const long maxpix = (long)B * (P.HO > c->H ? P.HO : c->H) * (P.WO > c->W ? P.WO : c->W);
+    Q.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks(maxpix) * P.C * sizeof(float));
+    Q.total = b.off + 256;
+}
+}  // namespace
+
+extern "C" size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c) {
+    RddbPlan P; if (rddb_plan(c, P)) return 0;
+    RddbBwdPlan Q; rddb_bwd_plan(c, P, Q); return Q.total;
+}
+
+extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
+                                      void* ws, float* y_nchw, void* st) {
+    RddbPlan P;
+    SG_TRY(rddb_plan(c, P));
+    SG_REQUIRE(x_nchw && params && ws && y_nchw, "srcgan_rddbnet_forward: null pointer");
+    SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_rddbnet_forward: workspace must be 256-byte aligned");
+    const int dt = c->dtype, nf = c->nf, gc = c->gc, B = c->B;
+    char* w8 = (char*)ws;
+    char* wp = w8 + P.wpk;
+    auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
+    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.C); };
+
+    // ---- pack weights for this call (f32 canonical -> dtype, MFMA-friendly)
+    SG_TRY(srcgan_pack_weight(params[P.p_first_w], wp + P.w_first_f, nf, c->in_ch, 3, 3, (long)c->in_ch * 9, 9, 3, 1, 0, dt, st));
+    for (int s = 0; s < P.ndn; ++s)
+        SG_TRY(srcgan_pack_weight(params[P.p_dn0 + 2 * s], wp + P.w_dn_f[s], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+    for (int i = 0; i < c->nb * 3; ++i)
+        for (int k = 0; k < 5; ++k) {
+            const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
+            SG_TRY(srcgan_pack_weight(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0, dt, st));
+        }
+    SG_TRY(srcgan_pack_weight(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+    for (int s = 0; s < P.nst; ++s)
+        for (int q = 0; q < 4; ++q)   // ConvTranspose2d weight [ci][co][2][2]; parity (a,b) = q: rows = co, k = ci
+            SG_TRY(srcgan_pack_weight(params[P.p_up0 + s], wp + P.w_up_f[s][q], nf, nf, 1, 1, 4, (long)nf * 4, 0, 0, q, dt, st));
+    SG_TRY(srcgan_pack_weight(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+
+    // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
+    SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
+    // conv_first (rddb.py:89,108).  The trunk input lives in channels [0,nf) of the first dense buffer so the
+    // first RDB reads it in place and the global skip (rddb.py:110) reads it back later.
+    const int H = P.Ht, W = P.Wt;
+    TRef trunk_in = Abuf(0);
+    TRef fea = P.ndn ? T_(P.fea0, nf) : trunk_in;
+    SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.xin, P.in_cs), B, c->H, c->W, P.in_cs).w(wp + P.w_first_f, params[P.p_first_b])
+               .out(fea, c->H, c->W, nf).pad(1, 1).run(st));
+    // optional HR->LR stages (build-defined RDDBNetA): 3x3 s2 p1 + bias + LeakyReLU
+    for (int s = 0; s < P.ndn; ++s) {
+        TRef o = (s == P.ndn - 1) ? trunk_in : T_(P.dn[s], nf);
+        SG_TRY(Conv(dt, 3, 3, 2).in(fea, B, c->H >> s, c->W >> s, nf).w(wp + P.w_dn_f[s], params[P.p_dn0 + 2 * s + 1])
+                   .out(o, c->H >> (s + 1), c->W >> (s + 1), nf).pad(1, 1).lrelu().run(st));
+        fea = o;
+    }
+    // RRDB trunk (rddb.py:62-68,78-82)
+    for (int i = 0; i < c->nb; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            const int r = i * 3 + j;
+            TRef A = Abuf(r);
+            for (int k = 0; k < 4; ++k) {
+                const int cin = nf + k * gc;
+                SG_TRY(Conv(dt, 3, 3, 1).in(A, B, H, W, cin).w(wp + P.w_rdb_f[r * 5 + k], params[P.p_rdb0 + (r * 5 + k) * 2 + 1])
+                           .out(sl(A, cin), H, W, gc).pad(1, 1).lrelu().run(st));
+            }
+            // conv5 + residual(s) -> channels [0,nf) of the next dense buffer (or the trunk output)
+            const bool last = (r == c->nb * 3 - 1);
+            TRef dst = last ? T_(P.T, nf) : Abuf(r + 1);
+            Conv cv(dt, 3, 3, 1);
+            cv.in(A, B, H, W, P.C).w(wp + P.w_rdb_f[r * 5 + 4], params[P.p_rdb0 + (r * 5 + 4) * 2 + 1]).out(dst, H, W, nf).pad(1, 1);
+            if (j < 2) cv.alpha(0.2f).res1(A, nf, 1.f);
+            else cv.alpha(0.04f).res1(A, nf, 0.2f).res2(Abuf(i * 3), nf, 1.f);   // RRDB: 0.2*(0.2*x5 + x_rdb3) + x_rrdb
+            SG_TRY(cv.run(st));
+        }
+    }
+    // trunk_conv + global skip (rddb.py:109-110)
+    SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.T, nf), B, H, W, nf).w(wp + P.w_trunk_f, params[P.p_trunk_b]).out(T_(P.U[0], nf), H, W, nf)
+               .pad(1, 1).res1(trunk_in, nf, 1.f).run(st));
+    // up-sampler: ConvTranspose2d(k2,s2) + LeakyReLU == 4 x (1x1 conv -> stride-2 scatter) (rddb.py:93-97,111-112)
+    for (int s = 0; s < P.nst; ++s) {
+        const int h = H << s, w = W << s;
+        for (int q = 0; q < 4; ++q)
+            SG_TRY(Conv(dt, 1, 1, 1).in(T_(P.U[s], nf), B, h, w, nf).w(wp + P.w_up_f[s][q]).out(T_(P.U[s + 1], nf), h, w, nf)
+                       .scatter(2, q >> 1, q & 1, 2 * h, 2 * w).lrelu().run(st));
+    }
+    // conv_last (no bias, rddb.py:98,113); padded output channels stay zero
+    SG_HIP(hipMemsetAsync(w8 + P.out, 0, (size_t)B * P.HO * P.WO * P.out_cs * P.esz, (hipStream_t)st));
+    SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.U[P.nst], nf), B, P.HO, P.WO, nf).w(wp + P.w_last_f).out(T_(P.out, P.out_cs), P.HO, P.WO, c->out_ch)
+               .pad(1, 1).run(st));
+    SG_TRY(srcgan_nhwc_to_nchw_f32(w8 + P.out, y_nchw, B, c->out_ch, P.HO, P.WO, P.out_cs, 0, dt, st));
+    return 0;
+}
+
+extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
+                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+    RddbPlan P;
+    SG_TRY(rddb_plan(c, P));
+    RddbBwdPlan Q;
+    rddb_bwd_plan(c, P, Q);
+    SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "srcgan_rddbnet_backward: null pointer");
+    SG_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)scratch % 256) == 0, "srcgan_rddbnet_backward: buffers must be 256-byte aligned");
+    const int dt = c->dtype, nf = c->nf, gc = c->gc, B = c->B, H = P.Ht, W = P.Wt;
+    char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
+    float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr);
+    auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
+    auto S_ = [&](size_t off, int cs) { return tref(s8 + off, cs); };
+    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.C); };
+    auto G = [&](int idx) { return grads[idx]; };
+    const long npix_t = (long)B * H * W;
+
+    // ---- packed dgrad weights (flipped / transposed views of the canonical tensors)
+    {
+        const WLayout L = lay_dgrad_s1(nf, 3, 3);
+        SG_TRY(srcgan_pack_weight(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off, dt, st));
+        for (int s = 0; s < P.nst; ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
+            SG_TRY(srcgan_pack_weight(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0, dt, st));
+        SG_TRY(srcgan_pack_weight(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off, dt, st));
+        for (int i = 0; i < c->nb * 3; ++i)
+            for (int k = 0; k < 5; ++k) {
+                const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
+                const WLayout Lk = lay_dgrad_s1(cin, 3, 3);
+                SG_TRY(srcgan_pack_weight(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_d[i * 5 + k], cin, cout, 3, 3, Lk.sr, Lk.sk, Lk.sty, Lk.stx, Lk.off, dt, st));
+            }
+        for (int s = 0; s < P.ndn; ++s)
+            for (int q = 0; q < 4; ++q) {
+                // 3x3 s2 p1 dgrad, output parity (a,b): rows with ky = a+1 (mod 2).  a=0: ky=1 (1 tap); a=1: ky=2,0 (2 taps)
+                const int a = q >> 1, bb = q & 1;
+                const int ty = a ? 2 : 1, tx = bb ? 2 : 1;
+                const long off = (a ? 2 : 1) * 3 + (bb ? 2 : 1);
+                SG_TRY(srcgan_pack_weight(params[P.p_dn0 + 2 * s], wp + P.w_dn_d[s][q], nf, nf, ty, tx, 9, (long)nf * 9, -6, -2, off, dt, st));
+            }
+        if (dx_nchw) {
+            const WLayout L0 = lay_dgrad_s1(c->in_ch, 3, 3);
+            SG_TRY(srcgan_pack_weight(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off, dt, st));
+        }
+    }
+
+    // ---- dy: NCHW f32 -> NHWC
+    TRef dout = S_(Q.dout, P.out_cs);
+    SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dout.p, B, c->out_ch, P.HO, P.WO, P.out_cs, dt, st));
+    // conv_last
+    TRef Ul = T_(P.U[P.nst], nf);
+    if (G(P.p_last_w))
+        SG_TRY(wgrad_call(dt, dout, P.HO, P.WO, c->out_ch, Ul, B, P.HO, P.WO, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_last_w), st));
+    {
+        Conv cv(dt, 3, 3, 1);
+        cv.in(dout, B, P.HO, P.WO, P.out_cs).w(wp + P.w_last_d).out(S_(Q.dU[P.nst], nf), P.HO, P.WO, nf).pad(1, 1);
+        if (P.nst > 0) cv.mask(Ul, 0);        // LeakyReLU after the last deconv
+        SG_TRY(cv.run(st));
+    }
+    // up-sampler stages, last to first
+    for (int s = P.nst - 1; s >= 0; --s) {
+        const int h = H << s, w = W << s;
+        TRef dHR = S_(Q.dU[s + 1], nf), Us = T_(P.U[s], nf);
+        if (G(P.p_up0 + s))   // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2
+            SG_TRY(wgrad_call(dt, Us, h, w, nf, dHR, B, 2 * h, 2 * w, nf, 2, 2, 2, 0, 0, WLayout{(long)nf * 4, 4, 2, 1, 0}, 1.f, slab, G(P.p_up0 + s), st));
+        Conv cv(dt, 2, 2, 2);
+        cv.in(dHR, B, 2 * h, 2 * w, nf).w(wp + P.w_up_d[s]).out(S_(Q.dU[s], nf), h, w, nf).pad(0, 0);
+        if (s > 0) cv.mask(Us, 0);
+        SG_TRY(cv.run(st));
+    }
+    // U0 = fea + trunk_conv(T): d(trunk_conv out) = dU0, d(fea) += dU0 (joined at the end)
+    TRef dU0 = S_(Q.dU[0], nf), Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
+    if (G(P.p_trunk_w))
+        SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st));
+    if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
+    SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(dT, H, W, nf).pad(1, 1).run(st));
+
+    // ---- RRDB trunk backward.  dcur = gradient w.r.t. the current block output (nf channels).
+    TRef dcur = dT;
+    int dcur_buf = -1;       // which of the 3 rotating dense-grad buffers holds dcur (-1: dT)
+    for (int i = c->nb - 1; i >= 0; --i) {
+        const TRef d_rrdb = dcur;
+        const int rrdb_buf = dcur_buf;
+        TRef dprev = d_rrdb;       // dOut of the RDB being processed
+        int prev_buf = rrdb_buf;
+        for (int j = 2; j >= 0; --j) {
+            const int r = i * 3 + j;
+            TRef A = Abuf(r);
+            int gb = 0;
+            while (gb == rrdb_buf || gb == prev_buf) ++gb;
+            TRef Gd = tref(s8 + Q.Pg[gb], P.C);
+            // scale of d(x5) relative to dprev, and of the block-input residual
+            const float a5 = (j == 2) ? 0.04f : 0.2f;
+            const float bres = (j == 2) ? 0.2f : 1.f;
+            const int pbase = P.p_rdb0 + r * 10;
+            // conv5
+            if (G(pbase + 8))
+                SG_TRY(wgrad_call(dt, dprev, H, W, nf, A, B, H, W, P.C, 3, 3, 1, 1, 1, lay_fwd(P.C, 3, 3), a5, slab, G(pbase + 8), st));
+            if (G(pbase + 9)) SG_TRY(bias_grad(dt, dprev, npix_t, nf, a5, G(pbase + 9), colscr, st));
+            SG_TRY(Conv(dt, 3, 3, 1).in(dprev, B, H, W, nf).w(wp + P.w_rdb_d[r * 5 + 4]).out(Gd, H, W, P.C).pad(1, 1)
+                       .alpha(a5).res1(dprev, nf, bres).mask(A, nf + 3 * gc).run(st));
+            // conv4 .. conv1
+            for (int k = 3; k >= 0; --k) {
+                const int cin = nf + k * gc;
+                TRef dyk = sl(Gd, cin);               // gradient of x_{k+1} (already multiplied by LeakyReLU')
+                if (G(pbase + 2 * k))
+                    SG_TRY(wgrad_call(dt, dyk, H, W, gc, A, B, H, W, cin, 3, 3, 1, 1, 1, lay_fwd(cin, 3, 3), 1.f, slab, G(pbase + 2 * k), st));
+                if (G(pbase + 2 * k + 1)) SG_TRY(bias_grad(dt, dyk, npix_t, gc, 1.f, G(pbase + 2 * k + 1), colscr, st));
+                Conv cv(dt, 3, 3, 1);
+                cv.in(dyk, B, H, W, gc).w(wp + P.w_rdb_d[r * 5 + k]).out(Gd, H, W, cin).pad(1, 1).res1(Gd, cin, 1.f);
+                if (k > 0) cv.mask(A, cin - gc);
+                else if (j == 0) cv.res2(d_rrdb, nf, 1.f);      // RRDB skip: d(x_rrdb) += d(out_rrdb)
+                SG_TRY(cv.run(st));
+            }
+            dprev = Gd; prev_buf = gb;
+        }
+        dcur = dprev; dcur_buf = prev_buf;
+    }
+    // gradient w.r.t. the trunk input feature = dcur + dU0 (global skip); for the HR->LR variant the trunk input
+    // is a LeakyReLU output, so its derivative is applied in the same pass.
+    TRef trunk_in = Abuf(0);
+    SG_TRY(srcgan_add_inplace(dcur.p, dcur.cs, dcur.coff, dU0.p, dU0.cs, dU0.coff, P.ndn ? trunk_in.p : nullptr, trunk_in.cs, 0, 0.2f,
+                              npix_t, nf, dt, st));
+    TRef dfea = dcur;
+    for (int s = P.ndn - 1; s >= 0; --s) {     // 3x3 s2 p1 stages of RDDBNetA, last to first
+        const int hi = c->H >> s, wi = c->W >> s, ho = hi / 2, wo = wi / 2;
+        TRef xin_s = s == 0 ? T_(P.fea0, nf) : T_(P.dn[s - 1], nf);
+        const int pw = P.p_dn0 + 2 * s;
+        if (G(pw)) SG_TRY(wgrad_call(dt, dfea, ho, wo, nf, xin_s, B, hi, wi, nf, 3, 3, 2, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(pw), st));
+        if (G(pw + 1)) SG_TRY(bias_grad(dt, dfea, (long)B * ho * wo, nf, 1.f, G(pw + 1), colscr, st));
+        TRef dst = S_(Q.dfea_dn[s], nf);
+        for (int q = 0; q < 4; ++q) {           // dgrad by output parity (a,b): sub-kernel of 1 or 2 taps per axis
+            const int a = q >> 1, bb = q & 1;
+            const int mh = (hi - a + 1) / 2, mw = (wi - bb + 1) / 2;
+            Conv cv(dt, a ? 2 : 1, bb ? 2 : 1, 1);
+            cv.in(dfea, B, ho, wo, nf).w(wp + P.w_dn_d[s][q]).out(dst, mh, mw, nf).pad(0, 0).scatter(2, a, bb, hi, wi);
+            if (s > 0) cv.mask(xin_s, 0);
+            SG_TRY(cv.run(st));
+        }
+        dfea = dst;
+    }
+    // conv_first
+    TRef xin = T_(P.xin, P.in_cs);
+    if (G(P.p_first_w))
+        SG_TRY(wgrad_call(dt, dfea, c->H, c->W, nf, xin, B, c->H, c->W, c->in_ch, 3, 3, 1, 1, 1, lay_fwd(c->in_ch, 3, 3), 1.f, slab, G(P.p_first_w), st));
+    if (G(P.p_first_b)) SG_TRY(bias_grad(dt, dfea, (long)B * c->H * c->W, nf, 1.f, G(P.p_first_b), colscr, st));
+    if (dx_nchw) {
+        TRef dxin = S_(Q.dxin, P.in_cs);
+        SG_HIP(hipMemsetAsync(dxin.p, 0, (size_t)B * c->H * c->W * P.in_cs * P.esz, (hipStream_t)st));
+        SG_TRY(Conv(dt, 3, 3, 1).in(dfea, B, c->H, c->W, nf).w(wp + P.w_first_d).out(dxin, c->H, c->W, c->in_ch).pad(1, 1).run(st));
+        SG_TRY(srcgan_nhwc_to_nchw_f32(dxin.p, dx_nchw, B, c->in_ch, c->H, c->W, P.in_cs, 0, dt, st));
+    }
+    return 0;
+}
+
+// ======================================================================================== NLayerDiscriminator
+namespace {
+struct DPlan {
+    int dtype, esz, L;                 // L convs
+    int ch[8], hh[8], ww[8], st[8];    // ch[l] -> ch[l+1]; spatial dims of activation l (0 = input)
+    int in_cs, out_cs;
+    int nparams;
+    size_t xin, Y[8], Z[8], stat[8], out, colscr, wpk, total;      // stat: mean[C], var[C], rstd[C]
+    size_t wf[8], wd[8][4];
+    int pw[8], pb[8], pg[8], pbeta[8];   // parameter indices (-1 if absent)
+    int bn_idx[8];                       // index among BN layers (-1 if none)
+};
+
+static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
+    SG_REQUIRE(c, "nlayerd: null cfg");
+    SG_REQUIRE(c->dtype == SRCGAN_F32 || c->dtype == SRCGAN_BF16, "nlayerd: bad dtype");
+    SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8, "nlayerd: input_nc must be in 1..8");
+    SG_REQUIRE(c->ndf > 0 && c->ndf % 8 == 0, "nlayerd: ndf must be a multiple of 8");
+    SG_REQUIRE(c->n_layers >= 1 && c->n_layers <= 5, "nlayerd: n_layers must be in 1..5");
+    SG_REQUIRE(c->B > 0 && c->H > 0 && c->W > 0, "nlayerd: bad B/H/W");
+    P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
+    P.L = c->n_layers + 2;
+    P.ch[0] = c->in_ch; P.ch[1] = c->ndf;
+    for (int n = 1; n < c->n_layers; ++n) { int m = 1 << n; if (m > 8) m = 8; P.ch[n + 1] = c->ndf * m; }
+    { int m = 1 << c->n_layers; if (m > 8) m = 8; P.ch[c->n_layers + 1] = c->ndf * m; }
+    P.ch[P.L] = 1;
+    P.hh[0] = c->H; P.ww[0] = c->W;
+    for (int l = 0; l < P.L; ++l) {
+        P.st[l] = l < c->n_layers ? 2 : 1;
+        P.hh[l + 1] = (P.hh[l] + 2 - 4) / P.st[l] + 1;
+        P.ww[l + 1] = (P.ww[l] + 2 - 4) / P.st[l] + 1;
+        SG_REQUIRE(P.hh[l + 1] > 0 && P.ww[l + 1] > 0, "nlayerd: input %dx%d too small for %d layers", c->H, c->W, c->n_layers);
+    }
+    P.in_cs = img_cs(c->in_ch); P.out_cs = 8;
+    const size_t e = P.esz, B = c->B;
+    Bump b;
+    P.xin = b.take(B * c->H * c->W * P.in_cs * e);
+    int n = 0, nbn = 0;
+    for (int l = 0; l < P.L; ++l) {
+        const bool bn = (l >= 1 && l <= P.L - 2), bias = (l == 0 || l == P.L - 1);
+        P.pw[l] = n++;
+        P.pb[l] = bias ? n++ : -1;
+        P.pg[l] = bn ? n++ : -1;
+        P.pbeta[l] = bn ? n++ : -1;
+        P.bn_idx[l] = bn ? nbn++ : -1;
+        const size_t sz = B * P.hh[l + 1] * P.ww[l + 1] * (l == P.L - 1 ? P.out_cs : P.ch[l + 1]) * e;
+        if (l == P.L - 1) P.out = b.take(sz);
+        else {
+            P.Y[l] = b.take(sz);
+            if (bn) { P.Z[l] = b.take(sz); P.stat[l] = b.take((size_t)3 * P.ch[l + 1] * sizeof(float)); }
+        }
+    }
+    P.nparams = n;
+    {
+        int cmax = 8; for (int l = 1; l < P.L; ++l) if (P.ch[l] > cmax) cmax = P.ch[l];
+        P.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks((long)B * P.hh[1] * P.ww[1]) * cmax * sizeof(float));
+    }
+    P.wpk = b.off;
+    Bump wb;
+    for (int l = 0; l < P.L; ++l) {
+        const int cin_r = l == 0 ? P.in_cs : P.ch[l];
+        P.wf[l] = wb.take(srcgan_packed_weight_bytes(P.ch[l + 1], cin_r, 16, c->dtype));
+        const int k_r = l == P.L - 1 ? P.out_cs : P.ch[l + 1];
+        if (P.st[l] == 1) P.wd[l][0] = wb.take(srcgan_packed_weight_bytes(P.ch[l], k_r, 16, c->dtype));
+        else for (int q = 0; q < 4; ++q) P.wd[l][q] = wb.take(srcgan_packed_weight_bytes(P.ch[l], k_r, 4, c->dtype));
+    }
+    P.total = align_up(P.wpk + wb.off + 256, 256);
+    return 0;
+}
+
+struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, total; };
+static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q) {
+    const size_t e = P.esz, B = c->B;
+    Bump b;
+    Q.dO = b.take(B * P.hh[P.L] * P.ww[P.L] * P.out_cs * e);
+    size_t mx = 0;
+    for (int l = 0; l < P.L - 1; ++l) { size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mx) mx = s; }
+    Q.g[0] = b.take(mx); Q.g[1] = b.take(mx);
+    Q.dxin = b.take(B * c->H * c->W * P.in_cs * e);
+    size_t slab = 0;
+    for (int l = 0; l < P.L; ++l) {
+        size_t s = wgrad_slab(c->B, P.hh[l + 1], P.ww[l + 1], P.ch[l + 1], P.ch[l], 4, 4, P.st[l]);
+        if (s > slab) slab = s;
+    }
+    Q.slab = b.take(slab);
+    int cmax = 8; for (int l = 1; l <= P.L; ++l) if (P.ch[l] > cmax) cmax = P.ch[l];
+    Q.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks((long)B * P.hh[1] * P.ww[1]) * cmax * sizeof(float));
+    Q.sums = b.take((size_t)2 * cmax * sizeof(float));
+    Q.total = b.off + 256;
+}
+}  // namespace
+
+extern "C" int srcgan_nlayerd_num_params(const srcgan_nlayerd_cfg* c) { DPlan P; if (d_plan(c, P)) return -1; return P.nparams; }
+extern "C" int srcgan_nlayerd_out_hw(const srcgan_nlayerd_cfg* c, int* oh, int* ow) {
+    DPlan P; SG_TRY(d_plan(c, P)); if (oh) *oh = P.hh[P.L]; if (ow) *ow = P.ww[P.L]; return 0;
+}
+extern "C" size_t srcgan_nlayerd_ws_bytes(const srcgan_nlayerd_cfg* c) { DPlan P; if (d_plan(c, P)) return 0; return P.total; }
+extern "C" size_t srcgan_nlayerd_bwd_scratch_bytes(const srcgan_nlayerd_cfg* c) {
+    DPlan P; if (d_plan(c, P)) return 0; DBwdPlan Q; d_bwd_plan(c, P, Q); return Q.total;
+}
+
+extern "C" int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, const float* const* params,
+                                      float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw, void* st) {
+    DPlan P;
+    SG_TRY(d_plan(c, P));
+    SG_REQUIRE(x_nchw && params && ws && y_nchw, "srcgan_nlayerd_forward: null pointer");
+    SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_nlayerd_forward: workspace must be 256-byte aligned");
+    const int dt = c->dtype, B = c->B;
+    char* w8 = (char*)ws; char* wp = w8 + P.wpk;
+    for (int l = 0; l < P.L; ++l)
+        SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wf[l], P.ch[l + 1], P.ch[l], 4, 4, (long)P.ch[l] * 16, 16, 4, 1, 0, dt, st));
+    SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
+    TRef cur = tref(w8 + P.xin, P.in_cs);
+    for (int l = 0; l < P.L; ++l) {
+        const int cin_r = l == 0 ? P.in_cs : P.ch[l], cout = P.ch[l + 1];
+        const int oh = P.hh[l + 1], ow = P.ww[l + 1];
+        const long npix = (long)B * oh * ow;
+        Conv cv(dt, 4, 4, P.st[l]);
+        cv.in(cur, B, P.hh[l], P.ww[l], cin_r).w(wp + P.wf[l], P.pb[l] >= 0 ? params[P.pb[l]] : nullptr).pad(1, 1);
+        if (l == 0) {                       // conv + bias + LeakyReLU (model/model.py:612)
+            TRef y = tref(w8 + P.Y[l], cout);
+            SG_TRY(cv.out(y, oh, ow, cout).lrelu().run(st));
+            cur = y;
+        } else if (l == P.L - 1) {          // final 1-channel prediction map (model/model.py:634)
+            SG_HIP(hipMemsetAsync(w8 + P.out, 0, (size_t)npix * P.out_cs * P.esz, (hipStream_t)st));
+            SG_TRY(cv.out(tref(w8 + P.out, P.out_cs), oh, ow, 1).run(st));
+        } else {                            // conv -> BatchNorm2d -> LeakyReLU (model/model.py:620-631)
+            TRef z = tref(w8 + P.Z[l], cout), y = tref(w8 + P.Y[l], cout);
+            SG_TRY(cv.out(z, oh, ow, cout).run(st));
+            float* mean = (float*)(w8 + P.stat[l]); float* var = mean + cout; float* rstd = var + cout;
+            const int bi = P.bn_idx[l];
+            const float* gamma = params[P.pg[l]]; const float* beta = params[P.pbeta[l]];
+            if (c->training) {
+                float* scr = (float*)(w8 + P.colscr);
+                SG_TRY(srcgan_col_reduce(0, z.p, cout, 0, nullptr, 0, 0, nullptr, nullptr, npix, cout, 1.f / (float)npix, mean, nullptr, scr, dt, st));
+                SG_TRY(srcgan_col_reduce(1, z.p, cout, 0, nullptr, 0, 0, mean, nullptr, npix, cout, 1.f / (float)npix, var, nullptr, scr, dt, st));
+                SG_TRY(srcgan_bn_finalize(mean, var, rstd, bn_running ? bn_running[2 * bi] : nullptr, bn_running ? bn_running[2 * bi + 1] : nullptr,
+                                          bn_nbt ? bn_nbt[bi] : nullptr, cout, npix, 0.1f, 1e-5f, st));
+                SG_TRY(srcgan_bn_apply_lrelu(z.p, y.p, mean, rstd, gamma, beta, npix, cout, cout, 0.2f, dt, st));
+            } else {
+                SG_REQUIRE(bn_running, "srcgan_nlayerd_forward: eval mode needs running statistics");
+                SG_TRY(srcgan_bn_eval_rstd(bn_running[2 * bi + 1], rstd, cout, 1e-5f, st));
+                SG_TRY(srcgan_bn_apply_lrelu(z.p, y.p, bn_running[2 * bi], rstd, gamma, beta, npix, cout, cout, 0.2f, dt, st));
+            }
+            cur = y;
+        }
+    }
+    SG_TRY(srcgan_nhwc_to_nchw_f32(w8 + P.out, y_nchw, B, 1, P.hh[P.L], P.ww[P.L], P.out_cs, 0, dt, st));
+    return 0;
+}
+
+extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
+                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+    DPlan P;
+    SG_TRY(d_plan(c, P));
+    SG_REQUIRE(c->training, "srcgan_nlayerd_backward: backward through eval-mode BatchNorm is not supported");
+    SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "srcgan_nlayerd_backward: null pointer");
+    DBwdPlan Q;
+    d_bwd_plan(c, P, Q);
+    const int dt = c->dtype, B = c->B;
+    char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
+    float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr); float* sums = (float*)(s8 + Q.sums);
+    // ---- packed dgrad weights
+    for (int l = 0; l < P.L; ++l) {
+        if (l == 0 && !dx_nchw) continue;
+        const int cin = P.ch[l], cout = P.ch[l + 1];
+        if (P.st[l] == 1)
+            SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wd[l][0], cin, cout, 4, 4, 16, (long)cin * 16, -4, -1, 15, dt, st));
+        else
+            for (int q = 0; q < 4; ++q) {   // stride-2 dgrad by output parity (a,b): 2x2 sub-kernel, ky = (a?2:3) - 2*ty
+                const int a = q >> 1, bb = q & 1;
+                const long off = (a ? 2 : 3) * 4 + (bb ? 2 : 3);
+                SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off, dt, st));
+            }
+    }
+    // ---- dy -> NHWC (1 channel, padded with zeros to 8)
+    const int Lh = P.hh[P.L], Lw = P.ww[P.L];
+    TRef dcur = tref(s8 + Q.dO, P.out_cs);
+    SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dcur.p, B, 1, Lh, Lw, P.out_cs, dt, st));
+    int dcur_c = P.out_cs;      // channels to read from dcur (padded)
+    for (int l = P.L - 1; l >= 0; --l) {
+        const int cin = P.ch[l], cout = P.ch[l + 1];
+        const int ih = P.hh[l], iw = P.ww[l], oh = P.hh[l + 1], ow = P.ww[l + 1];
+        const long npix = (long)B * oh * ow;
+        const bool bn = P.bn_idx[l] >= 0;
+        if (bn) {
+            // dcur = dL/dy * lrelu'(y) (mask fused in the producer).  BN backward (train): needs sum g, sum g*xhat
+            float* mean = (float*)(w8 + P.stat[l]); float* rstd = mean + 2 * cout;
+            TRef z = tref(w8 + P.Z[l], cout);
+            SG_TRY(srcgan_col_reduce(2, dcur.p, dcur.cs, 0, z.p, cout, 0, mean, rstd, npix, cout, 1.f, sums, sums + cout, colscr, dt, st));
+            if (grads[P.pbeta[l]]) SG_HIP(hipMemcpyAsync(grads[P.pbeta[l]], sums, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
+            if (grads[P.pg[l]]) SG_HIP(hipMemcpyAsync(grads[P.pg[l]], sums + cout, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
+            SG_TRY(srcgan_bn_bwd_apply(dcur.p, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, dt, st));
+        }
+        TRef xin_l = l == 0 ? tref(w8 + P.xin, P.in_cs) : tref(w8 + P.Y[l - 1], cin);
+        if (grads[P.pw[l]])
+            SG_TRY(wgrad_call(dt, dcur, oh, ow, cout, xin_l, B, ih, iw, cin, 4, 4, P.st[l], 1, 1, lay_fwd(cin, 4, 4), 1.f, slab, grads[P.pw[l]], st));
+        if (P.pb[l] >= 0 && grads[P.pb[l]]) SG_TRY(bias_grad(dt, dcur, npix, cout, 1.f, grads[P.pb[l]], colscr, st));
+        if (l == 0 && !dx_nchw) break;
+        // dgrad -> gradient of the layer input, times LeakyReLU' of that input (it is some layer's post-activation)
+        TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g[l & 1], cin);
+        if (l == 0) SG_HIP(hipMemsetAsync(dst.p, 0, (size_t)B * ih * iw * P.in_cs * P.esz, (hipStream_t)st));
+        TRef mz = l == 0 ? TNULL : tref(w8 + P.Y[l - 1], cin);
+        if (P.st[l] == 1) {
+            Conv cv(dt, 4, 4, 1);
+            cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, ih, iw, cin).pad(2, 2);
+            if (mz.p) cv.mask(mz, 0);
+            SG_TRY(cv.run(st));
+        } else {
+            for (int q = 0; q < 4; ++q) {
+                const int a = q >> 1, bb = q & 1;
+                const int mh = (ih - a + 1) / 2, mw = (iw - bb + 1) / 2;
+                if (mh <= 0 || mw <= 0) continue;
+                Conv cv(dt, 2, 2, 1);
+                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][q]).out(dst, mh, mw, cin).pad(a ? 0 : 1, bb ? 0 : 1).scatter(2, a, bb, ih, iw);
+                if (mz.p) cv.mask(mz, 0);
+                SG_TRY(cv.run(st));
+            }
+        }
+        dcur = dst; dcur_c = cin;
+    }
+    if (dx_nchw) SG_TRY(srcgan_nhwc_to_nchw_f32(s8 + Q.dxin, dx_nchw, B, c->in_ch, c->H, c->W, P.in_cs, 0, dt, st));
+    return 0;
+}

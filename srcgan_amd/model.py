@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference model classes on the hot path.
+
+Same class names, constructor signatures, ``state_dict`` keys / shapes / dtypes and NCHW f32
+tensor interface as the reference, so ``eval(opt.SRModel)(1, 1, opt.up)``
+(trainCas.py:30) and reference ``.pth`` checkpoints keep working -- but ``forward`` / backward run
+as one native call each into libsrcgan_amd.so (hand-written gfx950 kernels).  The ``nn.Conv2d`` /
+``nn.BatchNorm2d`` children are *parameter holders only* (they give the reference's key names and
+its default initialisation); their own ``forward`` is never used and there is no CPU fallback.
+
+  RDDBNet              <- reference src/model/rddb.py:85-114
+  NLayerDiscriminator  <- reference src/model/model.py:595-639
+  RDDBNetA             <- named by reference src/train.py:11,173 but defined nowhere; build-defined
+                          HR->LR mirror (strided 3x3 s2 conv + LeakyReLU per /2 stage, trunk at LR).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+__all__ = ["RDDBNet", "RDDBNetA", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv", "get_deconv_params"]
+
+
+def get_deconv_params(upscale_factor):
+    """(kernel_size, stride, output_padding) of the reference's deconv helper (rddb.py:9-25)."""
+    table = {2: (2, 2), 4: (2, 4), 8: (4, 8)}
+    if upscale_factor not in table:
+        raise ValueError(f"unsupported upscale_factor {upscale_factor}")
+    k, s = table[upscale_factor]
+    return k, s, s - k
+
+
+def deconv(in_planes, out_planes, upscale_factor=2):
+    """Parameter holder equal to the reference's deconv() (rddb.py:28-38)."""
+    k, s, opad = get_deconv_params(upscale_factor)
+    return nn.ConvTranspose2d(in_planes, out_planes, kernel_size=k, stride=s, padding=0, bias=False, output_padding=opad)
+
+
+class _HolderOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise NotImplementedError(
+            f"{type(self).__name__} is a parameter holder of the native srcgan_amd network; call the whole "
+            "network (RDDBNet / NLayerDiscriminator), which runs as fused gfx950 kernels.")
+
+
+class ResidualDenseBlock_5(_HolderOnly):
+    """Holder for conv1..conv5 of one dense block (rddb.py:48-60)."""
+
+    def __init__(self, nf=64, gc=32, bias=True):
+        super().__init__()
+        for k in range(5):
+            setattr(self, f"conv{k + 1}", nn.Conv2d(nf + k * gc, gc if k < 4 else nf, 3, 1, 1, bias=bias))
+
+
+class RRDB(_HolderOnly):
+    """Holder for RDB1..RDB3 (rddb.py:71-76)."""
+
+    def __init__(self, nf, gc=32):
+        super().__init__()
+        for j in (1, 2, 3):
+            setattr(self, f"RDB{j}", ResidualDenseBlock_5(nf, gc))
+
+
+def _kaiming_like_reference(module: nn.Module) -> None:
+    # rddb.py:100-105: kaiming-normal(fan_out, relu) on every nn.Conv2d weight; biases and
+    # ConvTranspose2d weights keep torch's default init.
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class _RddbFn(torch.autograd.Function):
+    """One native forward / one native backward for the whole generator."""
+
+    @staticmethod
+    def forward(ctx, x, cfg_items, *params):
+        N.require_cuda(x, "RDDBNet.forward")
+        lib = N.lib()
+        in_ch, out_ch, up, nf, nb, gc, dtype, down = cfg_items
+        if x.dim() != 4 or x.shape[1] != in_ch:
+            raise ValueError(f"RDDBNet expects [B,{in_ch},H,W], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, _, H, W = x.shape
+        cfg = N.RddbCfg(in_ch, out_ch, up, nf, nb, gc, B, H, W, dtype, down)
+        for p in params:
+            N.require_cuda(p, "RDDBNet parameter")
+        plist = [p.detach().contiguous() for p in params]
+        if any(p.dtype != torch.float32 for p in plist):
+            raise TypeError("RDDBNet parameters must be float32 (canonical weights stay f32)")
+        ws = N.workspace(lib.srcgan_rddbnet_ws_bytes(C.byref(cfg)), x.device)
+        f = (up if down == 0 else 1)
+        HO, WO = (H * f, W * f) if down <= 1 else (H // down, W // down)
+        y = torch.empty(B, out_ch, HO, WO, dtype=torch.float32, device=x.device)
+        N.check(lib.srcgan_rddbnet_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(),
+                                           N.stream_ptr(x.device)), "srcgan_rddbnet_forward")
+        ctx.cfg, ctx.ws, ctx.n = cfg, ws, len(plist)
+        ctx.save_for_backward(*plist)
+        ctx.hook = _grad_hooks.get("rddb")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = N.lib()
+        params = list(ctx.saved_tensors)
+        cfg = ctx.cfg
+        if ctx.ws is None:
+            raise RuntimeError("RDDBNet backward called twice (activations were released)")
+        dy = dy.contiguous().float()
+        need_dx = ctx.needs_input_grad[0]
+        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[2 + i] else None
+                                               for i, p in enumerate(params)]
+        scratch = N.workspace(lib.srcgan_rddbnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
+        dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
+        N.check(lib.srcgan_rddbnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
+                                            scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
+                                            N.stream_ptr(dy.device)), "srcgan_rddbnet_backward")
+        ctx.ws = None
+        if ctx.hook is not None:
+            ctx.hook(grads)
+        return (dx, None, *grads)
+
+
+# optional callbacks run on the freshly computed parameter gradients inside backward
+# (srcgan_amd.dist installs the gradient all-reduce here so it overlaps with the rest of backward)
+_grad_hooks = {}
+
+
+class RDDBNet(nn.Module):
+    """RRDB generator, drop-in for reference ``model.RDDBNet`` (rddb.py:85-114).
+
+    ``forward(x[B,in_ch,H,W] f32 NCHW) -> [B,ou_ch,H*up,W*up]``.  ``dtype``: 'fp32' (default; exact
+    f32 MFMA, <=1e-3 of the CPU reference) or 'bf16' (perf mode)."""
+
+    def __init__(self, in_ch, ou_ch, upscale_factor, nf=64, nb=3, gc=32, dtype=None):
+        super().__init__()
+        self.conv_first = nn.Conv2d(in_ch, nf, 3, 1, 1, bias=True)
+        self.RRDB_trunk = nn.Sequential(*[RRDB(nf=nf, gc=gc) for _ in range(nb)])
+        self.trunk_conv = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.upscale_factor = upscale_factor
+        ups = []
+        for _ in range(int(math.log2(upscale_factor))):
+            ups += [deconv(nf, nf, upscale_factor=2), nn.LeakyReLU(negative_slope=0.2, inplace=True)]
+        self.upscale_layers = nn.Sequential(*ups)
+        self.conv_last = nn.Conv2d(nf, ou_ch, 3, 1, 1, bias=False)
+        _kaiming_like_reference(self)
+        self._cfg = (in_ch, ou_ch, upscale_factor, nf, nb, gc)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def _down(self):
+        return 0
+
+    def forward(self, x):
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down())
+        # parameters in state_dict order == the order the native planner assumes
+        return _RddbFn.apply(x, cfg, *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
+
+
+class RDDBNetA(RDDBNet):
+    """HR->LR generator G_B of the cycle (reference train.py:173,178 names ``RDDBNetA`` but ships no
+    definition -> build-defined, "parity unpinned" vs the reference; pinned against oracle.rddbneta_forward).
+    conv_first -> [conv3x3 s2 + bias + LeakyReLU] x log2(down) -> RRDB trunk at LR -> trunk_conv + skip -> conv_last."""
+
+    def __init__(self, in_ch, ou_ch, down_factor, nf=64, nb=3, gc=32, dtype=None):
+        super().__init__(in_ch, ou_ch, 1, nf=nf, nb=nb, gc=gc, dtype=dtype)
+        self.down_factor = down_factor
+        downs = []
+        for _ in range(int(math.log2(down_factor))):
+            downs += [nn.Conv2d(nf, nf, 3, 2, 1, bias=True), nn.LeakyReLU(negative_slope=0.2, inplace=True)]
+        self.down_layers = nn.Sequential(*downs)
+        _kaiming_like_reference(self.down_layers)
+
+    def _down(self):
+        return max(1, self.down_factor)
+
+    def forward(self, x):
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down())
+        # native order: conv_first, down_layers, trunk, trunk_conv, conv_last
+        ps = [self.conv_first.weight, self.conv_first.bias, *self.down_layers.parameters(),
+              *self.RRDB_trunk.parameters(), self.trunk_conv.weight, self.trunk_conv.bias, self.conv_last.weight]
+        return _RddbFn.apply(x, cfg, *ps)
+
+
+class _NLayerDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg_items, running, nbt, *params):
+        N.require_cuda(x, "NLayerDiscriminator.forward")
+        lib = N.lib()
+        in_ch, ndf, n_layers, dtype, training = cfg_items
+        if x.dim() != 4 or x.shape[1] != in_ch:
+            raise ValueError(f"NLayerDiscriminator expects [B,{in_ch},H,W], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, _, H, W = x.shape
+        cfg = N.NLayerDCfg(in_ch, ndf, n_layers, B, H, W, dtype, int(training))
+        plist = [p.detach().contiguous() for p in params]
+        oh, ow = C.c_int(), C.c_int()
+        N.check(lib.srcgan_nlayerd_out_hw(C.byref(cfg), C.byref(oh), C.byref(ow)), "srcgan_nlayerd_out_hw")
+        ws = N.workspace(lib.srcgan_nlayerd_ws_bytes(C.byref(cfg)), x.device)
+        y = torch.empty(B, 1, oh.value, ow.value, dtype=torch.float32, device=x.device)
+        N.check(lib.srcgan_nlayerd_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), N.ptr_array(running),
+                                           N.ptr_array(nbt), ws.data_ptr(), y.data_ptr(), N.stream_ptr(x.device)),
+                "srcgan_nlayerd_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(*plist)
+        ctx.hook = _grad_hooks.get("nlayerd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = N.lib()
+        params = list(ctx.saved_tensors)
+        cfg = ctx.cfg
+        if ctx.ws is None:
+            raise RuntimeError("NLayerDiscriminator backward called twice (activations were released)")
+        dy = dy.contiguous().float()
+        need_dx = ctx.needs_input_grad[0]
+        grads = [torch.empty_like(p) if ctx.needs_input_grad[4 + i] else None for i, p in enumerate(params)]
+        scratch = N.workspace(lib.srcgan_nlayerd_bwd_scratch_bytes(C.byref(cfg)), dy.device)
+        dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
+        N.check(lib.srcgan_nlayerd_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
+                                            scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
+                                            N.stream_ptr(dy.device)), "srcgan_nlayerd_backward")
+        ctx.ws = None
+        if ctx.hook is not None:
+            ctx.hook(grads)
+        return (dx, None, None, None, *grads)
+
+
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN discriminator, drop-in for reference ``model.model.NLayerDiscriminator``
+    (model/model.py:595-639): conv4x4 s2 + LeakyReLU | (n-1) x [conv4x4 s2, BatchNorm2d, LeakyReLU] |
+    conv4x4 s1, BN, LeakyReLU | conv4x4 s1 -> 1 channel.  BatchNorm uses per-replica batch statistics
+    in train mode and updates the running buffers like nn.BatchNorm2d."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, dtype=None):
+        super().__init__()
+        if isinstance(norm_layer, functools.partial):
+            norm_layer = norm_layer.func
+        if norm_layer is not nn.BatchNorm2d:
+            raise NotImplementedError("native NLayerDiscriminator implements the BatchNorm2d variant the reference uses")
+        kw, padw = 4, 1
+        seq = [nn.Conv2d(input_nc, ndf, kw, 2, padw), nn.LeakyReLU(0.2, True)]
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 2, padw, bias=False), nn.BatchNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        prev, mult = mult, min(2 ** n_layers, 8)
+        seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 1, padw, bias=False), nn.BatchNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [nn.Conv2d(ndf * mult, 1, kw, 1, padw)]
+        self.model = nn.Sequential(*seq)
+        self._cfg = (input_nc, ndf, n_layers)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, input):
+        bns = [m for m in self.model if isinstance(m, nn.BatchNorm2d)]
+        running = [t for m in bns for t in (m.running_mean, m.running_var)]
+        nbt = [m.num_batches_tracked for m in bns]
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self.training)
+        return _NLayerDFn.apply(input, cfg, running, nbt, *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"

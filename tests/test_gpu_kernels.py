@@ -1,0 +1,250 @@
+"""GPU parity of the single kernels, through the C ABI, against a CPU f32 restatement
+(torch CPU ops == what the reference's nn.Conv2d / ConvTranspose2d / losses execute).
+Tolerances: f32 mode 1e-3 relative (north-star gate; observed ~1e-6); bf16 mode 2e-2 relative to
+the tensor's max (bf16 has 8 significant bits; reported separately, not held to 1e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-3, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from srcgan_amd import ops as o
+    return o
+
+
+def _q(t, dt):
+    """quantise reference inputs like the kernel sees them"""
+    return t.to(torch.bfloat16).float() if dt == "bf16" else t
+
+
+def _nhwc(ops, t, cs=None, dt="fp32"):
+    return ops.to_nhwc(t.cuda(), cs, dt)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_layout_roundtrip(ops, dt):
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 13, 37)
+    n = _nhwc(ops, x, 8, dt)
+    assert n.shape == (2, 13, 37, 8)
+    assert float(n[..., 3:].float().abs().max()) == 0.0
+    back = ops.to_nchw(n, 3).cpu()
+    assert rel_err(back, _q(x, dt)) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,hw", [(64, 32, (12, 10)), (96, 32, (9, 33)), (128, 32, (8, 32)), (160, 32, (17, 40)),
+                                         (192, 64, (16, 35)), (16, 8, (7, 5)), (24, 8, (12, 12)), (48, 16, (20, 36))])
+def test_conv3x3_dense_slice(ops, dt, cin, cout, hw):
+    """RDB conv: read channel prefix [0,cin) of a dense buffer, write slice [cin,cin+cout), bias + LeakyReLU."""
+    torch.manual_seed(1)
+    H, W = hw
+    ctot = cin + cout
+    buf = torch.rand(2, ctot, H, W) - 0.5
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    b = torch.randn(cout) * 0.1
+    dense = _nhwc(ops, buf, ctot, dt)
+    ops.conv_igemm(dense, ops.pack_conv2d_fwd(w.cuda(), dt), dense, kh=3, kw=3, Cin=cin, Cout=cout, y_coff=cin,
+                   pad=(1, 1), bias=b.cuda(), act=True)
+    ref = F.leaky_relu(F.conv2d(_q(buf[:, :cin], dt), _q(w, dt), b, 1, 1), 0.2)
+    got = ops.to_nchw(dense, cout, cin).cpu()
+    assert rel_err(got, ref) < TOL[dt]
+    # the prefix must be untouched
+    assert rel_err(ops.to_nchw(dense, cin, 0).cpu(), _q(buf[:, :cin], dt)) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_conv3x3_residual_epilogue(ops, dt):
+    """conv5 of RDB3: 0.04*(conv+bias) + 0.2*x_rdb + 1.0*x_rrdb (rddb.py:68,82)."""
+    torch.manual_seed(2)
+    x = torch.rand(1, 192, 11, 34) - 0.5
+    r2 = torch.rand(1, 64, 11, 34)
+    w = torch.randn(64, 192, 3, 3) * 0.05
+    b = torch.randn(64) * 0.1
+    xd, r2d = _nhwc(ops, x, 192, dt), _nhwc(ops, r2, 64, dt)
+    y = torch.zeros(1, 11, 34, 64, dtype=xd.dtype, device="cuda")
+    ops.conv_igemm(xd, ops.pack_conv2d_fwd(w.cuda(), dt), y, kh=3, kw=3, Cin=192, Cout=64, pad=(1, 1), bias=b.cuda(), alpha=0.04,
+                   r1=xd, r1_cend=64, beta1=0.2, r2=r2d, r2_cend=64, beta2=1.0)
+    xq = _q(x, dt)
+    ref = (F.conv2d(xq, _q(w, dt), b, 1, 1) * 0.2 + xq[:, :64]) * 0.2 + _q(r2, dt)
+    assert rel_err(ops.to_nchw(y).cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,s,hw", [(8, 64, 4, 2, (64, 64)), (64, 128, 4, 2, (32, 30)), (128, 256, 4, 1, (9, 12)),
+                                             (256, 1, 4, 1, (8, 8)), (16, 32, 4, 2, (20, 36)), (8, 64, 3, 1, (16, 12)),
+                                             (64, 3, 3, 1, (10, 50)), (64, 64, 3, 2, (16, 24))])
+def test_conv_generic(ops, dt, cin, cout, k, s, hw):
+    torch.manual_seed(3)
+    H, W = hw
+    x = torch.rand(2, cin, H, W) - 0.5
+    w = torch.randn(cout, cin, k, k) * 0.1
+    b = torch.randn(cout)
+    OH, OW = (H + 2 - k) // s + 1, (W + 2 - k) // s + 1
+    ycs = max(8, cout)
+    y = torch.zeros(2, OH, OW, ycs, dtype=torch.bfloat16 if dt == "bf16" else torch.float32, device="cuda")
+    ops.conv_igemm(_nhwc(ops, x, cin, dt), ops.pack_conv2d_fwd(w.cuda(), dt), y, kh=k, kw=k, stride=s, Cout=cout, pad=(1, 1), bias=b.cuda())
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, s, 1)
+    assert rel_err(ops.to_nchw(y, cout).cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_deconv_k2s2_as_pixel_shuffle(ops, dt):
+    """ConvTranspose2d(k2,s2,p0,no bias)+LeakyReLU == 4 parity 1x1 convs with a stride-2 scatter (rddb.py:28-38)."""
+    torch.manual_seed(4)
+    x = torch.rand(1, 64, 5, 7) - 0.5
+    w = torch.randn(64, 64, 2, 2) * 0.1      # [cin, cout, 2, 2]
+    xd = _nhwc(ops, x, 64, dt)
+    y = torch.zeros(1, 10, 14, 64, dtype=xd.dtype, device="cuda")
+    for q in range(4):
+        wp = ops.pack_weight(w.cuda(), 64, 64, 1, 1, 4, 64 * 4, 0, 0, q, dt)
+        ops.conv_igemm(xd, wp, y, kh=1, kw=1, Cout=64, OH=5, OW=7, act=True, os=2, oa=q >> 1, ob=q & 1)
+    ref = F.leaky_relu(F.conv_transpose2d(_q(x, dt), _q(w, dt), None, 2, 0), 0.2)
+    assert rel_err(ops.to_nchw(y).cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,s,hw", [(64, 32, 3, 1, (12, 10)), (192, 64, 3, 1, (9, 33)), (64, 128, 4, 2, (32, 30)),
+                                             (128, 256, 4, 1, (9, 12)), (8, 64, 4, 2, (20, 36)), (64, 64, 3, 2, (16, 24))])
+def test_dgrad_and_wgrad(ops, dt, cin, cout, k, s, hw):
+    """dgrad through conv_igemm with transposed packs (stride 2: 4 output-parity classes) and the wgrad kernel,
+    against autograd of F.conv2d on the CPU."""
+    torch.manual_seed(5)
+    H, W = hw
+    x = (torch.rand(2, cin, H, W) - 0.5).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k) * 0.1).requires_grad_(True)
+    xq, wq = _q(x.detach(), dt).requires_grad_(True), _q(w.detach(), dt).requires_grad_(True)
+    y = F.conv2d(xq, wq, None, s, 1)
+    dy = _q(torch.rand_like(y) - 0.5, dt)
+    y.backward(dy)
+    OH, OW = y.shape[2:]
+    dyd = _nhwc(ops, dy, cout, dt)
+    dx = torch.zeros(2, H, W, cin, dtype=dyd.dtype, device="cuda")
+    wc = w.detach().cuda()
+    if s == 1:
+        ops.conv_igemm(dyd, ops.pack_conv2d_dgrad_s1(wc, dt), dx, kh=k, kw=k, Cout=cin, OH=H, OW=W, pad=(k - 2, k - 2))
+    else:
+        for q in range(4):
+            a, b = q >> 1, q & 1
+            if k == 4:
+                wp = ops.pack_weight(wc, cin, cout, 2, 2, 16, cin * 16, -8, -2, (2 if a else 3) * 4 + (2 if b else 3), dt)
+                kh_, kw_, pad = 2, 2, (0 if a else 1, 0 if b else 1)
+            else:
+                kh_, kw_ = (2 if a else 1), (2 if b else 1)
+                wp = ops.pack_weight(wc, cin, cout, kh_, kw_, 9, cin * 9, -6, -2, (2 if a else 1) * 3 + (2 if b else 1), dt)
+                pad = (0, 0)
+            ops.conv_igemm(dyd, wp, dx, kh=kh_, kw=kw_, Cout=cin, OH=(H - a + 1) // 2, OW=(W - b + 1) // 2, pad=pad, os=2, oa=a, ob=b)
+    assert rel_err(ops.to_nchw(dx).cpu(), xq.grad) < TOL[dt]
+    gw = torch.zeros(cout, cin, k, k, device="cuda")
+    ops.conv_wgrad(dyd, _nhwc(ops, x.detach(), cin, dt), gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(1, 1),
+                   layout=(cin * k * k, k * k, k, 1, 0))
+    assert rel_err(gw.cpu(), wq.grad) < TOL[dt]
+    assert rel_err(ops.col_sum(dyd, cout).cpu(), dy.sum((0, 2, 3))) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_wgrad_small_channels_and_split(ops, dt):
+    """3-channel image input (padded to 8) and a forced multi-split reduction."""
+    torch.manual_seed(6)
+    x = torch.rand(3, 3, 40, 70)
+    dy = _q(torch.rand(3, 16, 40, 70) - 0.5, dt)
+    xq = _q(x, dt)
+    w = torch.zeros(16, 3, 3, 3, requires_grad=True)
+    F.conv2d(xq, w, None, 1, 1).backward(dy)
+    for ns in (1, 7):
+        gw = torch.zeros(16, 3, 3, 3, device="cuda")
+        ops.conv_wgrad(_nhwc(ops, dy, 16, dt), _nhwc(ops, x, 8, dt), gw, kh=3, kw=3, Cout=16, Cin=3, pad=(1, 1),
+                       layout=(27, 9, 3, 1, 0), nsplit=ns)
+        assert rel_err(gw.cpu(), w.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_deconv_backward(ops, dt):
+    """dgrad (2x2 s2 conv over dy) and wgrad (roles swapped) of the k2 s2 transposed conv."""
+    torch.manual_seed(7)
+    x = _q(torch.rand(2, 64, 6, 9) - 0.5, dt).requires_grad_(True)
+    w = _q(torch.randn(64, 64, 2, 2) * 0.1, dt).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, 2, 0)
+    dy = _q(torch.rand_like(y) - 0.5, dt)
+    y.backward(dy)
+    dyd, xd = _nhwc(ops, dy, 64, dt), _nhwc(ops, x.detach(), 64, dt)
+    dx = torch.zeros(2, 6, 9, 64, dtype=dyd.dtype, device="cuda")
+    wp = ops.pack_weight(w.detach().cuda(), 64, 64, 2, 2, 64 * 4, 4, 2, 1, 0, dt)
+    ops.conv_igemm(dyd, wp, dx, kh=2, kw=2, stride=2, Cout=64, OH=6, OW=9)
+    assert rel_err(ops.to_nchw(dx).cpu(), x.grad) < TOL[dt]
+    gw = torch.zeros(64, 64, 2, 2, device="cuda")
+    ops.conv_wgrad(xd, dyd, gw, kh=2, kw=2, stride=2, Cout=64, Cin=64, layout=(64 * 4, 4, 2, 1, 0))
+    assert rel_err(gw.cpu(), w.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_dgrad_accumulate_and_mask(ops, dt):
+    """dense-gradient epilogue: G[0:cin) += conv^T(dy); channels >= c0 times LeakyReLU'(forward activation)."""
+    torch.manual_seed(8)
+    cin, cout = 96, 32
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    g0 = _q(torch.rand(1, cin + cout, 10, 33) - 0.5, dt)
+    act = torch.rand(1, cin + cout, 10, 33) - 0.5
+    gd, ad = _nhwc(ops, g0, cin + cout, dt), _nhwc(ops, act, cin + cout, dt)
+    ops.conv_igemm(gd, ops.pack_conv2d_dgrad_s1(w.cuda(), dt), gd, kh=3, kw=3, Cin=cout, x_coff=cin, Cout=cin, pad=(1, 1),
+                   r1=gd, r1_cend=cin, beta1=1.0, mz=ad, mz_c0=cin - 32)
+    dy = g0[:, cin:]
+    ref = g0[:, :cin] + F.conv_transpose2d(dy, _q(w, dt), None, 1, 1)
+    m = torch.where(_q(act, dt)[:, :cin] > 0, 1.0, 0.2)
+    m[:, :cin - 32] = 1.0
+    assert rel_err(ops.to_nchw(gd, cin, 0).cpu(), ref * m) < TOL[dt]
+
+
+def test_losses_golden():
+    from srcgan_amd import L1Loss, MSELoss, PSNRLoss, GANLoss
+    g = load_golden("losses")
+    b = torch.from_numpy(g["b"]).cuda()
+    for name, crit in (("l1", L1Loss()), ("mse", MSELoss())):
+        a = torch.from_numpy(g["a"]).cuda().requires_grad_(True)
+        v = crit(a, b)
+        v.backward()
+        assert abs(float(v) - float(g[name])) < 1e-5
+        assert rel_err(a.grad.cpu(), g[name + "_da"]) < 1e-5
+    a = torch.from_numpy(g["a"]).cuda()
+    assert abs(float(PSNRLoss()(a, b)) - float(g["psnr"])) < 1e-3
+    gl = GANLoss("lsgan", device="cuda")
+    for name, real in (("gan_real", True), ("gan_fake", False)):
+        a = torch.from_numpy(g["a"]).cuda().requires_grad_(True)
+        v = gl(a, real)
+        (v * 1.0).backward()
+        assert abs(float(v) - float(g[name])) < 1e-5
+        assert rel_err(a.grad.cpu(), g[name + "_da"]) < 1e-5
+
+
+def test_loss_large_and_tail():
+    """size-independent check at a large, non-multiple-of-4 length: linearity of the mean."""
+    from srcgan_amd import L1Loss
+    torch.manual_seed(9)
+    n = 3 * 1024 * 1024 + 3
+    a = torch.rand(n, device="cuda")
+    b = torch.rand(n, device="cuda")
+    v = float(L1Loss()(a.view(1, 1, 1, -1), b.view(1, 1, 1, -1)))
+    ref = float((a.double() - b.double()).abs().mean())
+    assert abs(v - ref) < 1e-5
+
+
+def test_preproc_golden(ops):
+    g = load_golden("preproc")
+    img = torch.from_numpy(g["img"]).cuda()
+    gray = ops.rgb_to_gray(img)
+    assert rel_err(gray.cpu(), g["gray"]) < 1e-6
+    for up in (2, 4):
+        assert rel_err(ops.bilinear_down(gray, up).cpu(), g[f"bil_down{up}"]) < 1e-6
+        assert rel_err(ops.nearest_resize(img, 1.0 / up).cpu(), g[f"near_down{up}"]) < 1e-6
+    big = torch.rand(2, 3, 64, 96, device="cuda")
+    assert rel_err(ops.nearest_resize(big, 2).cpu(), F.interpolate(big.cpu(), scale_factor=2)) < 1e-7

@@ -1,0 +1,194 @@
+"""GPU parity of the drop-in modules (one native call per forward / backward) against
+(a) the golden vectors captured from the imported reference and (b) the CPU oracle on fresh
+seeded inputs at full channel width.  f32 mode: <= 1e-3 relative (north-star gate).
+bf16 mode: reported against a looser bound (bf16 storage of 8 significant bits through up to
+~50 stacked convs); it is the perf mode, not the parity mode."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, sub, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _load(module, sd):
+    missing = module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+@pytest.mark.parametrize("tag", ["rddbnet_x2", "rddbnet_x4", "rddbnet_x2_w32"])
+def test_rddbnet_golden_f32(tag):
+    from srcgan_amd import RDDBNet, L1Loss
+    g = load_golden(tag)
+    ic, oc, up, nf, nb, gc = [int(v) for v in g["cfg"]]
+    net = _load(RDDBNet(ic, oc, up, nf=nf, nb=nb, gc=gc, dtype="fp32"), sub(g, "sd/"))
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.cpu(), g["y"]) < F32_TOL
+    loss = L1Loss()(y, torch.from_numpy(g["t"]).cuda())
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < F32_TOL
+    grads = sub(g, "grad/")
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+
+
+def test_rdb_full_width_golden_f32():
+    """One full-width dense block (nf=64, gc=32) from the reference, embedded in a generator whose other
+    layers are the oracle's: checks the MFMA path at the real (Cin,Cout) pairs against reference numbers."""
+    from srcgan_amd import ops
+    g = load_golden("rdb_full")
+    sd = sub(g, "sd/")
+    x = torch.from_numpy(g["x"])
+    dense = ops.to_nhwc(torch.cat([x, torch.zeros(1, 128, *x.shape[2:])], 1).cuda(), 192, "fp32")
+    out = torch.zeros(1, x.shape[2], x.shape[3], 64, device="cuda")
+    for k in range(5):
+        cin = 64 + 32 * k
+        wp = ops.pack_conv2d_fwd(sd[f"conv{k+1}.weight"].cuda(), "fp32")
+        b = sd[f"conv{k+1}.bias"].cuda()
+        if k < 4:
+            ops.conv_igemm(dense, wp, dense, kh=3, kw=3, Cin=cin, Cout=32, y_coff=cin, pad=(1, 1), bias=b, act=True)
+        else:
+            ops.conv_igemm(dense, wp, out, kh=3, kw=3, Cin=192, Cout=64, pad=(1, 1), bias=b, alpha=0.2, r1=dense, r1_cend=64, beta1=1.0)
+    assert rel_err(ops.to_nchw(out).cpu(), g["y"]) < F32_TOL
+
+
+@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 6e-2)])
+def test_rddbnet_full_width_vs_oracle(dt, tol):
+    """nf=64, gc=32, nb=2, x4 on an odd-sized input; forward, input grad and every parameter grad."""
+    from srcgan_amd import RDDBNet
+    torch.manual_seed(0)
+    sd = oracle.rddbnet_state(3, 3, 4, 64, 2, 32, seed=3)
+    net = _load(RDDBNet(3, 3, 4, nf=64, nb=2, gc=32, dtype=dt), sd)
+    x = torch.rand(2, 3, 19, 35)
+    t = torch.rand(2, 3, 76, 140)
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = oracle.rddbnet_forward(ref_sd, xr, 4)
+    oracle.l1_loss(yr, t).backward()
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    from srcgan_amd import L1Loss
+    L1Loss()(y, t.cuda()).backward()
+    assert rel_err(y.cpu(), yr) < tol
+    assert rel_err(xg.grad.cpu(), xr.grad) < tol * 2
+    worst = max(rel_err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+    assert worst < tol * 2, worst
+
+
+@pytest.mark.parametrize("tag", ["nlayerd_3", "nlayerd_2"])
+def test_nlayerd_golden_f32(tag):
+    from srcgan_amd import NLayerDiscriminator, GANLoss
+    g = load_golden(tag)
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    net = _load(NLayerDiscriminator(ic, ndf, nl, dtype="fp32"), sub(g, "sd/"))
+    net.train()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.cpu(), g["y"]) < F32_TOL
+    loss = GANLoss("lsgan", device="cuda")(y, True)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < F32_TOL
+    grads = sub(g, "grad/")
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+    after = sub(g, "sd_after/")
+    sd_now = net.state_dict()
+    for k, v in after.items():
+        assert rel_err(sd_now[k].double().cpu(), v.double()) < 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        assert rel_err(net(x.detach()).cpu(), g["y_eval"]) < F32_TOL
+
+
+@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 6e-2)])
+def test_nlayerd_full_width_vs_oracle(dt, tol):
+    """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch, incl. a frozen pass (dgrad only)."""
+    from srcgan_amd import NLayerDiscriminator, GANLoss
+    sd = oracle.nlayer_d_state(3, 64, 3, seed=5)
+    net = _load(NLayerDiscriminator(3, 64, 3, dtype=dt), sd)
+    torch.manual_seed(1)
+    x = torch.rand(2, 3, 96, 128)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = oracle.nlayer_d_forward(ref_sd, xr, True)
+    oracle.gan_loss(yr, False).backward()
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    GANLoss("lsgan", device="cuda")(y, False).backward()
+    assert rel_err(y.cpu(), yr) < tol
+    assert rel_err(xg.grad.cpu(), xr.grad) < tol * 2
+    worst = max(rel_err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+    assert worst < tol * 2, worst
+    # frozen discriminator (train.py:330): no parameter grads, input grad still flows
+    for p in net.parameters():
+        p.requires_grad_(False)
+        p.grad = None
+    xg2 = x.cuda().requires_grad_(True)
+    GANLoss("lsgan", device="cuda")(net(xg2), True).backward()
+    assert xg2.grad is not None and all(p.grad is None for p in net.parameters())
+
+
+def test_paired_step_golden_f32():
+    """Two paired G+D optimisation steps (BASELINE config-1 structure) from the reference's initial weights:
+    losses and post-Adam weights."""
+    from srcgan_amd.train import PairedSRGAN
+    g = load_golden("paired_step")
+    m = PairedSRGAN(3, 3, 2, nf=16, nb=1, gc=8, ndf=16, n_layers=3, dtype="fp32", device="cuda")
+    m.netG.load_state_dict(sub(g, "g0/"))
+    m.netD.load_state_dict(sub(g, "d0/"))
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    for step in range(2):
+        m.optimize_parameters(x, y)
+        for k, mine in (("loss_G", m.loss_G), ("loss_D", m.loss_D), ("loss_G_GAN", m.loss_G_GAN), ("loss_L1", m.loss_L1)):
+            ref = float(g[f"{k}_{step}"])
+            assert abs(float(mine) - ref) < 1e-3 * max(1.0, abs(ref)), (k, step)
+        if step == 0:
+            assert rel_err(m.fake.cpu(), g["fake_0"]) < F32_TOL
+    for k, v in sub(g, "g1/").items():
+        assert rel_err(m.netG.state_dict()[k].cpu(), v) < F32_TOL, k
+    for k, v in sub(g, "d1/").items():
+        if v.is_floating_point():
+            assert rel_err(m.netD.state_dict()[k].cpu(), v) < F32_TOL, k
+
+
+def test_rddbneta_vs_oracle_f32():
+    """build-defined HR->LR generator (reference RDDBNetA has no source): parity vs the oracle restatement only."""
+    from srcgan_amd import RDDBNetA, L1Loss
+    sd = oracle.rddbneta_state(3, 3, 2, 32, 1, 16, seed=2)
+    net = RDDBNetA(3, 3, 2, nf=32, nb=1, gc=16, dtype="fp32")
+    net.load_state_dict(sd)
+    net.cuda()
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, 24, 40)
+    t = torch.rand(2, 3, 12, 20)
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = oracle.rddbneta_forward(ref_sd, xr, 2)
+    oracle.l1_loss(yr, t).backward()
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    L1Loss()(y, t.cuda()).backward()
+    assert rel_err(y.cpu(), yr) < F32_TOL
+    assert rel_err(xg.grad.cpu(), xr.grad) < F32_TOL
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), ref_sd[k].grad) < F32_TOL, k
+
+
+def test_cpu_tensor_fails_loudly():
+    from srcgan_amd import RDDBNet
+    net = RDDBNet(3, 3, 2, nf=16, nb=1, gc=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.rand(1, 3, 8, 8))
