@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paired SR-GAN training images/sec at x4, 256->1024 (BASELINE.json configs[1],
+"Sat2Aerx4": RDDBNet(3,3,4,nb=23) generator + 3-layer PatchGAN, bf16, batch 16 per MI355X).
+
+One "step" = one paired optimisation step on one synthetic batch resident in HBM:
+  G-step {G fwd, D(fake) fwd + dgrad, L1*10 + lsgan, G bwd, Adam} + D-step {D(real), D(fake.detach()) fwd/bwd, Adam}
+(SURVEY.md section 8d).  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch through
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+# algorithmic MACs per image, SURVEY.md section 8d / BASELINE.md section 3
+def mac_g(nb, up, cin, cout, P):
+    import math
+    return P * (576 * cin + 718848 * nb + 36864 + 16384 * sum(4 ** s for s in range(int(math.log2(up)))) + 576 * cout * up * up)
+
+
+def mac_d3(H):
+    return 3072 * (H // 2) ** 2 + 131072 * (H // 4) ** 2 + 524288 * (H // 8) ** 2 + 2097152 * (H // 8 - 1) ** 2 + 8192 * (H // 8 - 2) ** 2
+
+
+def cpu_baseline(nb, lr_hw, up, threads):
+    """The CPU oracle (restatement of the reference, pinned by golden vectors) timed on this host:
+    ONE paired step on ONE image of the same workload shape (bounded sample)."""
+    import oracle
+    torch.set_num_threads(threads)
+    st = oracle.make_paired_state(3, 3, up, 64, nb, 32, 64, 3, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(1, 3, lr_hw, lr_hw, generator=g)
+    y = torch.rand(1, 3, lr_hw * up, lr_hw * up, generator=g)
+    t0 = time.perf_counter()
+    oracle.paired_step(st, x, y)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 paired G+D step, batch 1, 3x{lr_hw}x{lr_hw}->3x{lr_hw*up}x{lr_hw*up}, nb={nb}, fp32 torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--nb", type=int, default=23)
+    ap.add_argument("--lr-size", type=int, default=256)
+    ap.add_argument("--up", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    from srcgan_amd import dist as sdist
+    from srcgan_amd import _native as N
+    from srcgan_amd.train import PairedSRGAN
+
+    rank, local, world = sdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the native path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)                         # identical init on every rank, then broadcast anyway
+    model = PairedSRGAN(3, 3, args.up, nf=64, nb=args.nb, gc=32, ndf=64, n_layers=3, dtype=args.dtype, device=dev)
+    if world > 1:
+        sdist.broadcast_module(model.netG)
+        sdist.broadcast_module(model.netD)
+        model.grad_sync = sdist.GradSync()
+    B, h, H = args.batch, args.lr_size, args.lr_size * args.up
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand(B, 3, h, h, generator=g).to(dev)           # synthetic, value range of dataset.py:131
+    y = torch.rand(B, 3, H, H, generator=g).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.optimize_parameters(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.optimize_parameters(x, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_g, loss_d = float(model.loss_G), float(model.loss_D)
+
+    # ---- per-kernel roofline: one extra step with HIP events around every conv launch (launch stream)
+    roofline, kernels = None, []
+    if rank == 0 and not args.no_kernel_profile:
+        N.prof_enable(True)
+        model.optimize_parameters(x, y)
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        kernels = sorted(N.prof_collect(), key=lambda k: -k["ms"])
+        if kernels:
+            k = kernels[0]
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            roofline = {"bound": "mfma", "kernel": k["cls"], "launches": k["count"], "avg_ms": k["ms"] / k["count"],
+                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "algorithmic_gbytes_per_s": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
+    barrier()
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        per_img_mac = 3 * mac_g(args.nb, args.up, 3, 3, h * h) + 8 * mac_d3(H)
+        out = {
+            "metric": "paired SR-CycleGAN train images/sec at x4 256->1024",
+            "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Sat2Aerx{args.up} paired G+D step (BASELINE configs[1]): 23-block RRDB generator + 3-layer PatchGAN, "
+                                   f"3x{h}x{h}->3x{H}x{H}, batch {B}/GPU" if args.nb == 23 else
+                                   f"Sat2Aerx{args.up} paired G+D step, nb={args.nb}, 3x{h}x{h}->3x{H}x{H}, batch {B}/GPU",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "algorithmic_tflop_per_image": 2 * per_img_mac / 1e12,
+            "step_tflops": 2 * per_img_mac * imgs / elapsed / 1e12,
+            "loss_G": loss_g, "loss_D": loss_d,
+            "roofline": roofline,
+            "kernels": [{"kernel": k["cls"], "launches": k["count"], "ms": round(k["ms"], 3),
+                         "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 1)} for k in kernels[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.nb, h, args.up, os.cpu_count() or 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

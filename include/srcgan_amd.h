@@ -98,6 +98,7 @@ int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
  * ------------------------------------------------------------------------- */
 typedef struct srcgan_wgrad_desc {
     const void* dy; const void* x; float* slab; float* grad;
+    float* bias_grad;                       /* optional: alpha * sum_p dy[p,co], fused (3x3 kernels only) */
     int dtype;
     int kh, kw, stride;
     int B, H, W, Cin, x_cs, x_coff;         /* x tensor; Cin = true input channels */
@@ -206,6 +207,16 @@ int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, con
                            float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw, void* stream);
 int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
                             void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Launch profiling for bench.py: when enabled, every conv_igemm / conv_wgrad launch is bracketed by
+ * HIP events on its launch stream.  collect() synchronises, aggregates per kernel class
+ * (template instance) and returns the number of classes; get(i) reads one aggregate:
+ * launches, total ms, total algorithmic flop and bytes.
+ * ------------------------------------------------------------------------- */
+int srcgan_prof_enable(int on);
+int srcgan_prof_collect(void);
+int srcgan_prof_get(int i, const char** cls, long* count, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -56,7 +56,7 @@ class ConvDesc(C.Structure):
 
 
 class WgradDesc(C.Structure):
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("grad", C.c_void_p),
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("grad", C.c_void_p), ("bias_grad", C.c_void_p),
                 ("dtype", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("x_cs", C.c_int), ("x_coff", C.c_int),
                 ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("dy_cs", C.c_int), ("dy_coff", C.c_int),
@@ -104,6 +104,9 @@ SIGNATURES = {
     "srcgan_rgb_to_gray": (_I, [_P, _P, _I, _I, _I, _P]),
     "srcgan_bilinear_down": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "srcgan_nearest_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "srcgan_prof_enable": (_I, [_I]),
+    "srcgan_prof_collect": (_I, []),
+    "srcgan_prof_get": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "srcgan_rddbnet_num_params": (_I, [C.POINTER(RddbCfg)]),
     "srcgan_rddbnet_ws_bytes": (_S, [C.POINTER(RddbCfg)]),
     "srcgan_rddbnet_bwd_scratch_bytes": (_S, [C.POINTER(RddbCfg)]),
@@ -165,3 +168,18 @@ def workspace(nbytes: int, device) -> torch.Tensor:
         raise RuntimeError("srcgan_amd: native planner rejected the configuration: "
                            + (lib().srcgan_last_error() or b"").decode())
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().srcgan_prof_enable(int(on)), "srcgan_prof_enable")
+
+
+def prof_collect():
+    """-> list of dicts {cls, count, ms, flops, bytes} aggregated per kernel class since the last collect."""
+    l = lib()
+    out = []
+    for i in range(l.srcgan_prof_collect()):
+        cls, cnt, ms, fl, by = C.c_char_p(), C.c_long(), C.c_double(), C.c_double(), C.c_double()
+        check(l.srcgan_prof_get(i, C.byref(cls), C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)), "srcgan_prof_get")
+        out.append({"cls": cls.value.decode(), "count": cnt.value, "ms": ms.value, "flops": fl.value, "bytes": by.value})
+    return out

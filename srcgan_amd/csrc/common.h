@@ -54,3 +54,8 @@ void srcgan_set_error(const char* fmt, ...);
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- optional per-launch profiling
+// (bench.py: HIP events on the launch stream around the hot kernels; off by default -> zero cost)
+int sg_prof_start(const char* cls, double flops, double bytes, hipStream_t st);   // returns token or -1
+void sg_prof_stop(int token, hipStream_t st);

@@ -26,7 +26,7 @@ struct ConvP {
     int pad_y, pad_x, os, oa, ob;
     int r1Cs, r1coff, r1cend, r2Cs, r2coff, r2cend, mzCs, mzcoff, mzc0;
     float alpha, beta1, beta2, slope, mslope;
-    int act, vec, nchunk, tiles_x, tiles_y;
+    int act, vec, nchunk, tiles_x, tiles_y, ctiles;
 };
 
 
@@ -39,16 +39,24 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     constexpr int WROWS = (WPK ? KW : NTAP) * COT;
     constexpr int NPH = IHT * IWT * 4;     // 16-byte pieces of the halo tile
     constexpr int NPW = WROWS * 4;         // 16-byte pieces of one weight stage
+    constexpr int HIT = (NPH + 255) / 256, WIT = (NPW + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_h = smem;
     char* lds_w = smem + IHT * IWT * PIXB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    int t = blockIdx.x;
+    // XCD-aware block -> tile map: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a contiguous
+    // run of tiles so neighbouring tiles' halos and the Cout tiles of one spatial tile hit the same L2.
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int ct = L % p.ctiles;
+    int t = L / p.ctiles;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int b = t / p.tiles_y;
-    const int ct = blockIdx.y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int gy0 = oy0 * S - p.pad_y, gx0 = ox0 * S - p.pad_x;
 
@@ -63,36 +71,86 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
     const char* wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
 
-    for (int c = 0; c < p.nchunk; ++c) {
-        __syncthreads();   // all waves are done reading the previous chunk
-        // ---- stage the input halo tile for this channel chunk (zero outside the image / past Cin)
+    // ---- per-thread staging descriptors (independent of the channel chunk).  Loads are issued
+    // unconditionally from a clamped address and zeroed by a select afterwards: no branches, so the
+    // compiler keeps all of a stage's loads in flight together.
+    int h_goff[HIT];                  // byte offset of this thread's halo piece in image b (chunk 0), -1 = outside
+    const int part = tid & 3;
 #pragma unroll
-        for (int it = 0; it < (NPH + 255) / 256; ++it) {
+    for (int it = 0; it < HIT; ++it) {
+        const int pc = it * 256 + tid, pix = pc >> 2;
+        const int iy = pix / IWT, ix = pix - iy * IWT;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        const bool ok = pc < NPH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        h_goff[it] = ok ? ((gy * p.W + gx) * p.xCs * (int)sizeof(T) + part * 16) : -1;
+    }
+    u32x4 hreg[HIT];
+    u32x4 wreg[WPK ? 1 : WIT];
+    auto issue_halo = [&](int c) {
+        const bool cok = c * D::KCE + part * D::EPP < p.Cin;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int off = (h_goff[it] >= 0 && cok) ? h_goff[it] + c * 64 : 0;
+            hreg[it] = *(const u32x4*)(xb + off);
+        }
+    };
+    auto write_halo = [&](int c) {
+        const bool cok = c * D::KCE + part * D::EPP < p.Cin;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
             const int pc = it * 256 + tid;
-            if (pc < NPH) {
-                const int pix = pc >> 2, part = pc & 3;
-                const int iy = pix / IWT, ix = pix - iy * IWT;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                const int ch = c * D::KCE + part * D::EPP;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.Cin)
-                    v = *(const u32x4*)(xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T));
-                *(u32x4*)(lds_h + pix * PIXB + part * 16) = v;
+            u32x4 v = hreg[it];
+            if (!(h_goff[it] >= 0 && cok)) v = u32x4{0u, 0u, 0u, 0u};
+            if (HIT * 256 == NPH || pc < NPH) *(u32x4*)(lds_h + (pc >> 2) * PIXB + part * 16) = v;
+        }
+    };
+    auto issue_w = [&](int c) {
+        if constexpr (!WPK) {
+            const char* ws = wb + (size_t)c * NTAP * COT * 64;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pc = it * 256 + tid;
+                wreg[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
             }
+        }
+    };
+    auto write_w = [&]() {
+        if constexpr (!WPK) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pc = it * 256 + tid;
+                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wreg[it];
+            }
+        }
+    };
+
+    issue_halo(0);
+    issue_w(0);
+    for (int c = 0; c < p.nchunk; ++c) {
+        // registers (chunk c) -> LDS; the previous chunk's readers passed the barrier at the loop bottom
+        write_halo(c);
+        write_w();
+        __syncthreads();
+        if (c + 1 < p.nchunk) {       // prefetch the next chunk: in flight while this chunk's MFMAs run
+            issue_halo(c + 1);
+            issue_w(c + 1);
         }
         const char* wc = wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
-            if (WPK || ky == 0) {
-                if (WPK && ky > 0) __syncthreads();   // previous kernel row's weights consumed
-                const char* ws = wc + (WPK ? (size_t)ky * KW * COT * 64 : 0);
+            if constexpr (WPK) {      // 4x4 kernels: one kernel row of weights at a time (LDS budget)
+                if (ky > 0) __syncthreads();
+                const char* ws = wc + (size_t)ky * KW * COT * 64;
+                u32x4 wv[WIT];
 #pragma unroll
-                for (int it = 0; it < (NPW + 255) / 256; ++it) {
+                for (int it = 0; it < WIT; ++it) {
                     const int pc = it * 256 + tid;
-                    if (pc < NPW) {
-                        const u32x4 v = *(const u32x4*)(ws + (size_t)pc * 16);
-                        *(u32x4*)(lds_w + (pc >> 2) * PIXB + (pc & 3) * 16) = v;
-                    }
+                    wv[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
+                }
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int pc = it * 256 + tid;
+                    if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wv[it];
                 }
                 __syncthreads();
             }
@@ -134,6 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
                 }
             }
         }
+        __syncthreads();   // all waves are done reading this chunk's LDS image
     }
 
     // ---- epilogue.  acc[m][q][4g+i] = D[cout = 32m + 8g + 4h + i][pixel = r]
@@ -211,8 +270,16 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     ConvP q = p;
     q.tiles_x = cdiv(p.OW, TW);
     q.tiles_y = cdiv(p.OH, TH);
-    dim3 grid((unsigned)((size_t)q.tiles_x * q.tiles_y * p.B), (unsigned)ctiles, 1);
+    q.ctiles = ctiles;
+    dim3 grid((unsigned)((size_t)q.tiles_x * q.tiles_y * p.B * ctiles), 1, 1);
+    char cls[96];
+    snprintf(cls, sizeof(cls), "conv_igemm<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", KH, KW, S, MT);
+    // algorithmic work: 2*pixels*taps*Cin*Cout flop; bytes: input read once + output written once
+    const double px = (double)p.B * p.OH * p.OW;
+    const int tok = sg_prof_start(cls, 2.0 * px * NTAP * p.Cin * p.Cout,
+                                  ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, q);
+    sg_prof_stop(tok, st);
     SG_LAUNCH_CHECK();
     return 0;
 }

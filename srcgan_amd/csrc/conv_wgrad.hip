@@ -22,7 +22,7 @@ struct WgradP {
     int B, H, W, Cin, xCs, xcoff;
     int OH, OW, Cout, dyCs, dycoff;
     int pad_y, pad_x;
-    int nsplit, tiles_x, tiles_y, ntiles, citiles, ctiles;
+    int nsplit, tiles_x, tiles_y, ntiles, citiles, ctiles, want_bias;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -36,23 +36,31 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T, int KH, int KW, int S, int MT, int TH, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
+// NCW compute waves split the taps; when BIASW an extra wave helps staging and (for the first Cin tile)
+// accumulates the bias gradient as a pseudo-tap whose B operand is all ones: D[co][*] = sum_p dy[p][co].
+template <typename T, int KH, int KW, int S, int MT, int TH, int NCW, bool BIASW>
+__global__ __launch_bounds__((NCW + (BIASW ? 1 : 0)) * 64) void conv_wgrad_k(const WgradP p) {
     using D = DT<T>;
+    constexpr int NW = NCW + (BIASW ? 1 : 0);
     constexpr int TW = 32, NTAP = KH * KW, COT = 32 * MT;
     constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
     constexpr int PB = 32 * (int)sizeof(T);          // bytes per pixel per 32-channel plane
     constexpr int PPP = PB / 16;                     // 16-byte pieces per pixel
-    constexpr int TPW = (NTAP + NW - 1) / NW;        // taps per wave
+    constexpr int TPW = (NTAP + NCW - 1) / NCW;      // taps per compute wave
     constexpr int NT = NW * 64;
     constexpr int NPD = MT * TH * TW * PPP;          // pieces of the dy tile
     constexpr int NPX = IHT * IWT * PPP;             // pieces of the x halo tile
+    constexpr int DIT = (NPD + NT - 1) / NT, XIT = (NPX + NT - 1) / NT;
+    static_assert(NT % PPP == 0, "piece part must be thread-invariant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_d = smem;                              // [MT][TH*TW][PB]
     char* lds_x = smem + MT * TH * TW * PB;          // [IHT*IWT][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int cit = blockIdx.x, ct = blockIdx.y, split = blockIdx.z;
+    const int part = tid % PPP;
+    const bool bias_wave = BIASW && wave == NCW;
+    const bool do_bias = bias_wave && cit == 0 && p.want_bias;
 
     f32x16 acc[TPW][MT];
 #pragma unroll
@@ -64,7 +72,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
 
     const int t_begin = (int)((long)p.ntiles * split / p.nsplit);
     const int t_end = (int)((long)p.ntiles * (split + 1) / p.nsplit);
-    for (int t = t_begin; t < t_end; ++t) {
+
+    // branch-free staging through registers, one tile ahead of the MFMAs
+    u32x4 dreg[DIT], xreg[XIT];
+    unsigned dmask = 0, xmask = 0;          // validity bits of the pieces held in dreg / xreg
+    auto issue = [&](int t) {
         int q = t;
         const int tx = q % p.tiles_x; q /= p.tiles_x;
         const int ty = q % p.tiles_y;
@@ -73,59 +85,83 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
         const int gy0 = oy0 * S - p.pad_y, gx0 = ox0 * S - p.pad_x;
         const char* dyb = (const char*)p.dy + ((size_t)b * p.OH * p.OW * p.dyCs + p.dycoff) * sizeof(T);
         const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
-        __syncthreads();
-        // ---- dy tile: plane m holds channels [ct*COT + 32m, +32)
+        dmask = 0; xmask = 0;
 #pragma unroll
-        for (int it = 0; it < (NPD + NT - 1) / NT; ++it) {
+        for (int it = 0; it < DIT; ++it) {
             const int pc = it * NT + tid;
-            if (pc < NPD) {
-                const int part = pc % PPP;
-                const int pix = (pc / PPP) % (TH * TW);
-                const int m = pc / (PPP * TH * TW);
-                const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
-                const int ch = ct * COT + m * 32 + part * D::EPP;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (oy < p.OH && ox < p.OW && ch < p.Cout)
-                    v = *(const u32x4*)(dyb + ((size_t)(oy * p.OW + ox) * p.dyCs + ch) * sizeof(T));
-                *(u32x4*)(lds_d + (m * TH * TW + pix) * PB + part * 16) = v;
-            }
+            const int pix = (pc / PPP) % (TH * TW);
+            const int m = pc / (PPP * TH * TW);
+            const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+            const int ch = ct * COT + m * 32 + part * D::EPP;
+            const bool ok = pc < NPD && oy < p.OH && ox < p.OW && ch < p.Cout;
+            dmask |= (ok ? 1u : 0u) << it;
+            dreg[it] = *(const u32x4*)(dyb + (ok ? ((size_t)(oy * p.OW + ox) * p.dyCs + ch) * sizeof(T) : 0));
         }
-        // ---- x halo tile: channels [cit*32, +32)
 #pragma unroll
-        for (int it = 0; it < (NPX + NT - 1) / NT; ++it) {
+        for (int it = 0; it < XIT; ++it) {
             const int pc = it * NT + tid;
-            if (pc < NPX) {
-                const int part = pc % PPP;
-                const int pix = pc / PPP;
-                const int iy = pix / IWT, ix = pix - iy * IWT;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                const int ch = cit * 32 + part * D::EPP;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.Cin)
-                    v = *(const u32x4*)(xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T));
-                *(u32x4*)(lds_x + pix * PB + part * 16) = v;
-            }
+            const int pix = pc / PPP;
+            const int iy = pix / IWT, ix = pix - iy * IWT;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const int ch = cit * 32 + part * D::EPP;
+            const bool ok = pc < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.Cin;
+            xmask |= (ok ? 1u : 0u) << it;
+            xreg[it] = *(const u32x4*)(xb + (ok ? ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T) : 0));
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int pc = it * NT + tid;
+            u32x4 v = dreg[it];
+            if (!((dmask >> it) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+            if (DIT * NT == NPD || pc < NPD) *(u32x4*)(lds_d + (pc / PPP) * PB + part * 16) = v;   // (m*TH*TW + pix) == pc / PPP
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int pc = it * NT + tid;
+            u32x4 v = xreg[it];
+            if (!((xmask >> it) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+            if (XIT * NT == NPX || pc < NPX) *(u32x4*)(lds_x + (pc / PPP) * PB + part * 16) = v;
+        }
+    };
+
+    if (t_begin < t_end) issue(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        commit();
         __syncthreads();
+        if (t + 1 < t_end) issue(t + 1);
 
         if constexpr (std::is_same<T, float>::value) {
             // mfma_32x32x2_f32: lane (r,h) supplies A[row r][k = h], B[k = h][col r]; one MFMA eats 2 pixels.
+            if (!bias_wave) {
 #pragma unroll 4
-            for (int kk = 0; kk < TH * TW / 2; ++kk) {
-                const int pix = 2 * kk + h;
-                const int py = pix / TW, px = pix % TW;
-                float a[MT];
+                for (int kk = 0; kk < TH * TW / 2; ++kk) {
+                    const int pix = 2 * kk + h;
+                    const int py = pix / TW, px = pix % TW;
+                    float a[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = *(const float*)(lds_d + (m * TH * TW + pix) * PB + r * 4);
+                    for (int m = 0; m < MT; ++m) a[m] = *(const float*)(lds_d + (m * TH * TW + pix) * PB + r * 4);
 #pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) {
-                    const int tap = wave + tl * NW;
-                    if (tap < NTAP) {
-                        const int ky = tap / KW, kx = tap % KW;
-                        const float bv = *(const float*)(lds_x + ((py * S + ky) * IWT + px * S + kx) * PB + r * 4);
+                    for (int tl = 0; tl < TPW; ++tl) {
+                        const int tap = wave + tl * NCW;
+                        if (tap < NTAP) {
+                            const int ky = tap / KW, kx = tap % KW;
+                            const float bv = *(const float*)(lds_x + ((py * S + ky) * IWT + px * S + kx) * PB + r * 4);
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[tl][m], 0, 0, 0);
+                            for (int m = 0; m < MT; ++m)
+                                acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[tl][m], 0, 0, 0);
+                        }
+                    }
+                }
+            } else if (do_bias) {
+#pragma unroll 4
+                for (int kk = 0; kk < TH * TW / 2; ++kk) {
+                    const int pix = 2 * kk + h;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = *(const float*)(lds_d + (m * TH * TW + pix) * PB + r * 4);
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[0][m], 0, 0, 0);
                     }
                 }
             }
@@ -135,38 +171,57 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
             // the address of pixel row q, channels 4pp..4pp+3 of the group's 16.
             const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
             const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
+            if (!bias_wave) {
 #pragma unroll 2
-            for (int kk = 0; kk < TH * 2; ++kk) {
-                const int py = kk >> 1, xh = (kk & 1) * 16;
-                const int px0 = xh + 8 * h + qq;           // first of this lane's two address pixels
-                bf16x8 a[MT];
+                for (int kk = 0; kk < TH * 2; ++kk) {
+                    const int py = kk >> 1, xh = (kk & 1) * 16;
+                    const int px0 = xh + 8 * h + qq;           // first of this lane's two address pixels
+                    bf16x8 a[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const char* base = lds_d + (m * TH * TW + py * TW + px0) * PB + choff;
-                    a[m] = tr_frag(base, base + 4 * PB);
+                    for (int m = 0; m < MT; ++m) {
+                        const char* base = lds_d + (m * TH * TW + py * TW + px0) * PB + choff;
+                        a[m] = tr_frag(base, base + 4 * PB);
+                    }
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl) {
+                        const int tap = wave + tl * NCW;
+                        if (tap < NTAP) {
+                            const int ky = tap / KW, kx = tap % KW;
+                            const char* base = lds_x + ((py * S + ky) * IWT + px0 * S + kx) * PB + choff;
+                            const bf16x8 bv = tr_frag(base, base + 4 * S * PB);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[tl][m], 0, 0, 0);
+                        }
+                    }
                 }
+            } else if (do_bias) {
+                bf16x8 ones;
 #pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) {
-                    const int tap = wave + tl * NW;
-                    if (tap < NTAP) {
-                        const int ky = tap / KW, kx = tap % KW;
-                        const char* base = lds_x + ((py * S + ky) * IWT + px0 * S + kx) * PB + choff;
-                        const bf16x8 bv = tr_frag(base, base + 4 * S * PB);
+                for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#pragma unroll 2
+                for (int kk = 0; kk < TH * 2; ++kk) {
+                    const int py = kk >> 1, xh = (kk & 1) * 16;
+                    const int px0 = xh + 8 * h + qq;
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[tl][m], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m) {
+                        const char* base = lds_d + (m * TH * TW + py * TW + px0) * PB + choff;
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(base, base + 4 * PB), ones, acc[0][m], 0, 0, 0);
                     }
                 }
             }
         }
+        __syncthreads();
     }
 
-    // ---- partial slab: [split][ct][cit][tap][co (COT)][ci (32)];  acc[.][m][4g+i] = D[co = 32m+8g+4h+i][ci = r]
+    // ---- partial slab: [split][ct][cit][tap (NTAP+1)][co (COT)][ci (32)];  acc[.][m][4g+i] = D[co = 32m+8g+4h+i][ci = r]
+    // (tap index NTAP = bias pseudo-tap, only written for cit == 0)
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl) {
-        const int tap = wave + tl * NW;
-        if (tap >= NTAP) continue;
-        float* sp = p.slab + ((((size_t)split * p.ctiles + ct) * p.citiles + cit) * NTAP + tap) * (COT * 32);
+        int tap = wave + tl * NCW;
+        if (bias_wave) { if (tl > 0 || !do_bias) continue; tap = NTAP; }
+        else if (tap >= NTAP) continue;
+        float* sp = p.slab + ((((size_t)split * p.ctiles + ct) * p.citiles + cit) * (NTAP + 1) + tap) * (COT * 32);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -178,30 +233,42 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_k(const WgradP p) {
 }
 
 struct WredP {
-    const float* slab; float* grad;
+    const float* slab; float* grad; float* bias_grad;
     int nsplit, ctiles, citiles, ntap, kw, COT, Cout, Cin;
     long sr, sk, sty, stx, off;
     float alpha; int accumulate;
 };
 
+// 64 slab elements x 4 split lanes per block; fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const WredP p) {
-    const long total = (long)p.ctiles * p.citiles * p.ntap * p.COT * 32;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        long q = e;
-        const int ci_l = (int)(q % 32); q /= 32;
-        const int co_l = (int)(q % p.COT); q /= p.COT;
-        const int tap = (int)(q % p.ntap); q /= p.ntap;
-        const int cit = (int)(q % p.citiles);
-        const int ct = (int)(q / p.citiles);
-        const int co = ct * p.COT + co_l, ci = cit * 32 + ci_l;
-        if (co >= p.Cout || ci >= p.Cin) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) s += p.slab[(size_t)sp * total + e];
-        const int ky = tap / p.kw, kx = tap % p.kw;
-        float* g = p.grad + p.off + co * p.sr + ci * p.sk + ky * p.sty + kx * p.stx;
-        const float v = s * p.alpha;
-        *g = p.accumulate ? (*g + v) : v;
+    __shared__ float red[4][64];
+    const long per_split = (long)p.ctiles * p.citiles * (p.ntap + 1) * p.COT * 32;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (e < per_split)
+        for (int sp = sl; sp < p.nsplit; sp += 4) s += p.slab[(size_t)sp * per_split + e];
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl != 0 || e >= per_split) return;
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    long q = e;
+    const int ci_l = (int)(q % 32); q /= 32;
+    const int co_l = (int)(q % p.COT); q /= p.COT;
+    const int tap = (int)(q % (p.ntap + 1)); q /= (p.ntap + 1);
+    const int cit = (int)(q % p.citiles);
+    const int ct = (int)(q / p.citiles);
+    const int co = ct * p.COT + co_l, ci = cit * 32 + ci_l;
+    if (co >= p.Cout) return;
+    const float v = s * p.alpha;
+    if (tap == p.ntap) {                      // bias pseudo-tap: every column holds the same sum
+        if (p.bias_grad && cit == 0 && ci_l == 0) p.bias_grad[co] = p.accumulate ? p.bias_grad[co] + v : v;
+        return;
     }
+    if (ci >= p.Cin) return;
+    const int ky = tap / p.kw, kx = tap % p.kw;
+    float* g = p.grad + p.off + co * p.sr + ci * p.sk + ky * p.sty + kx * p.stx;
+    *g = p.accumulate ? (*g + v) : v;
 }
 
 // ------------------------------------------------------------------ host side
@@ -209,7 +276,7 @@ static inline int wg_cot(int Cout) { return Cout <= 32 ? 32 : 64; }
 
 extern "C" size_t srcgan_conv_wgrad_slab_bytes(int Cout, int Cin, int kh, int kw, int nsplit) {
     const int cot = wg_cot(Cout);
-    return (size_t)nsplit * cdiv(Cout, cot) * cdiv(Cin, 32) * kh * kw * cot * 32 * sizeof(float);
+    return (size_t)nsplit * cdiv(Cout, cot) * cdiv(Cin, 32) * (kh * kw + 1) * cot * 32 * sizeof(float);
 }
 
 extern "C" int srcgan_conv_wgrad_nsplit(int B, int OH, int OW, int Cout, int Cin, int stride) {
@@ -223,13 +290,14 @@ extern "C" int srcgan_conv_wgrad_nsplit(int B, int OH, int OW, int Cout, int Cin
     return (int)want;
 }
 
-template <typename T, int KH, int KW, int S, int MT, int TH, int NW>
+template <typename T, int KH, int KW, int S, int MT, int TH, int NCW, bool BIASW>
 static int launch_wgrad(WgradP p, hipStream_t st) {
+    constexpr int NW = NCW + (BIASW ? 1 : 0);
     constexpr int TW = 32, PB = 32 * (int)sizeof(T);
     constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
     constexpr size_t SMEM = (size_t)MT * TH * TW * PB + (size_t)IHT * IWT * PB;
     static_assert(SMEM <= 160 * 1024, "wgrad tile exceeds LDS");
-    auto kern = conv_wgrad_k<T, KH, KW, S, MT, TH, NW>;
+    auto kern = conv_wgrad_k<T, KH, KW, S, MT, TH, NCW, BIASW>;
     static bool attr_set = false;
     if (!attr_set) {
         SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -240,26 +308,33 @@ static int launch_wgrad(WgradP p, hipStream_t st) {
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
     dim3 grid((unsigned)p.citiles, (unsigned)p.ctiles, (unsigned)p.nsplit);
+    char cls[96];
+    snprintf(cls, sizeof(cls), "conv_wgrad<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", KH, KW, S, MT);
+    const double px = (double)p.B * p.OH * p.OW;
+    const int tok = sg_prof_start(cls, 2.0 * px * KH * KW * p.Cin * p.Cout,
+                                  ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), SMEM, st, p);
+    sg_prof_stop(tok, st);
     SG_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename T, int MT>
 static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st) {
-#define SG_CASE(KH_, KW_, S_, TH_, NW_) \
-    if (kh == KH_ && kw == KW_ && s == S_) return launch_wgrad<T, KH_, KW_, S_, MT, TH_, NW_>(p, st);
-    SG_CASE(3, 3, 1, 8, 3)
-    SG_CASE(2, 2, 2, 4, 4)
-    SG_CASE(4, 4, 2, 4, 4)
-    SG_CASE(4, 4, 1, 8, 4)
-    SG_CASE(3, 3, 2, 4, 3)
+#define SG_CASE(KH_, KW_, S_, TH_, NCW_, BIASW_) \
+    if (kh == KH_ && kw == KW_ && s == S_) return launch_wgrad<T, KH_, KW_, S_, MT, TH_, NCW_, BIASW_>(p, st);
+    SG_CASE(3, 3, 1, 8, 3, true)
+    SG_CASE(2, 2, 2, 4, 4, false)
+    SG_CASE(4, 4, 2, 4, 4, false)
+    SG_CASE(4, 4, 1, 8, 4, false)
+    SG_CASE(3, 3, 2, 4, 3, true)
 #undef SG_CASE
     SG_FAIL("srcgan_conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, s);
 }
 
 extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     SG_REQUIRE(d && d->dy && d->x && d->slab && d->grad, "srcgan_conv_wgrad: null pointer");
+    SG_REQUIRE(!d->bias_grad || (d->kh == 3 && d->kw == 3), "srcgan_conv_wgrad: fused bias gradient is implemented for 3x3 kernels only");
     SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_wgrad: bad dtype %d", d->dtype);
     const int esz = d->dtype == SRCGAN_F32 ? 4 : 2, epp = 16 / esz;
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0 && d->nsplit > 0,
@@ -276,7 +351,7 @@ extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     p.dy = d->dy; p.x = d->x; p.slab = d->slab;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = cin_r; p.xCs = d->x_cs; p.xcoff = d->x_coff;
     p.OH = d->OH; p.OW = d->OW; p.Cout = cout_r; p.dyCs = d->dy_cs; p.dycoff = d->dy_coff;
-    p.pad_y = d->pad_y; p.pad_x = d->pad_x;
+    p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.want_bias = d->bias_grad != nullptr;
     const int cot = wg_cot(d->Cout);
     p.ctiles = cdiv(d->Cout, cot); p.citiles = cdiv(d->Cin, 32);
     const int th = d->stride == 2 ? 4 : 8;
@@ -290,13 +365,12 @@ extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
                                      : dispatch_wgrad<__bf16, 2>(p, d->kh, d->kw, d->stride, st);
     if (rc) return rc;
     WredP q;
-    q.slab = d->slab; q.grad = d->grad; q.nsplit = p.nsplit; q.ctiles = p.ctiles; q.citiles = p.citiles;
+    q.slab = d->slab; q.grad = d->grad; q.bias_grad = d->bias_grad; q.nsplit = p.nsplit; q.ctiles = p.ctiles; q.citiles = p.citiles;
     q.ntap = d->kh * d->kw; q.kw = d->kw; q.COT = cot; q.Cout = d->Cout; q.Cin = d->Cin;
     q.sr = d->sr; q.sk = d->sk; q.sty = d->sty; q.stx = d->stx; q.off = d->off;
     q.alpha = d->alpha; q.accumulate = d->accumulate;
-    const long total = (long)p.ctiles * p.citiles * q.ntap * cot * 32;
-    int blocks = (int)(cdivl(total, 256) > 2048 ? 2048 : cdivl(total, 256));
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(blocks), dim3(256), 0, st, q);
+    const long per_split = (long)p.ctiles * p.citiles * (q.ntap + 1) * cot * 32;
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
     SG_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,55 @@ extern "C" const char* srcgan_last_error(void) { return g_err; }
 extern "C" int srcgan_version(void) { return 100; }
 extern "C" int srcgan_dtype_size(int dtype) { return dtype == SRCGAN_F32 ? 4 : (dtype == SRCGAN_BF16 ? 2 : 0); }
 
+// --------------------------------------------------------------------------- launch profiling
+#include <vector>
+#include <string>
+#include <map>
+namespace {
+struct ProfRec { std::string cls; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+struct ProfAgg { std::string cls; long count; double ms, flops, bytes; };
+std::vector<ProfAgg> g_agg;
+}
+int sg_prof_start(const char* cls, double flops, double bytes, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    (void)hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void sg_prof_stop(int token, hipStream_t st) {
+    if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].e1, st);
+}
+extern "C" int srcgan_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+// Synchronises, aggregates the recorded launches per kernel class and clears the log.  Returns #classes.
+extern "C" int srcgan_prof_collect(void) {
+    std::map<std::string, ProfAgg> m;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        ProfAgg& a = m[r.cls];
+        a.cls = r.cls; a.count += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    g_agg.clear();
+    for (auto& kv : m) g_agg.push_back(kv.second);
+    return (int)g_agg.size();
+}
+extern "C" int srcgan_prof_get(int i, const char** cls, long* count, double* ms, double* flops, double* bytes) {
+    SG_REQUIRE(i >= 0 && i < (int)g_agg.size(), "srcgan_prof_get: index out of range");
+    if (cls) *cls = g_agg[i].cls.c_str();
+    if (count) *count = g_agg[i].count;
+    if (ms) *ms = g_agg[i].ms;
+    if (flops) *flops = g_agg[i].flops;
+    if (bytes) *bytes = g_agg[i].bytes;
+    return 0;
+}
+
 #define DISPATCH_DTYPE(dtype, ...) \
     if ((dtype) == SRCGAN_F32) { using T = float; __VA_ARGS__; } \
     else if ((dtype) == SRCGAN_BF16) { using T = __bf16; __VA_ARGS__; } \
@@ -174,22 +223,29 @@ __global__ __launch_bounds__(256) void col_reduce_k(const T* __restrict__ a, int
     }
 }
 
+// one block per 64 channels; 4 block-lanes split the partials, fixed order
 __global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ partial, int nblk, int C, float scale,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     float s0 = 0.f, s1 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        s0 += partial[(size_t)b * C + c];
-        if (out1) s1 += partial[((size_t)nblk + b) * C + c];
+    if (c < C)
+        for (int b = py; b < nblk; b += 4) {
+            s0 += partial[(size_t)b * C + c];
+            if (out1) s1 += partial[((size_t)nblk + b) * C + c];
+        }
+    red[0][py][cx] = s0; red[1][py][cx] = s1;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        out0[c] = ((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx])) * scale;
+        if (out1) out1[c] = ((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx])) * scale;
     }
-    out0[c] = s0 * scale;
-    if (out1) out1[c] = s1 * scale;
 }
 
 extern "C" int srcgan_col_reduce_blocks(long npix) {
     long b = cdivl(npix, 256);
-    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
 }
 
 extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, const void* z, int z_cs, int z_coff,
@@ -207,7 +263,7 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
         else hipLaunchKernelGGL((col_reduce_k<T, 2>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
     });
     SG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
+    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 64)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
     SG_LAUNCH_CHECK();
     return 0;
 }

@@ -58,11 +58,12 @@ struct Bump {   // workspace bump allocator (256-byte aligned)
 };
 
 static int wgrad_call(int dtype, TRef dy, int OH, int OW, int Cout, TRef x, int B, int H, int W, int Cin, int kh, int kw,
-                      int stride, int pad_y, int pad_x, WLayout lay, float alpha, float* slab, float* grad, void* st) {
+                      int stride, int pad_y, int pad_x, WLayout lay, float alpha, float* slab, float* grad, void* st,
+                      float* bias_grad = nullptr) {
     srcgan_wgrad_desc d;
     memset(&d, 0, sizeof(d));
     d.dy = dy.p; d.dy_cs = dy.cs; d.dy_coff = dy.coff; d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff;
-    d.slab = slab; d.grad = grad; d.dtype = dtype; d.kh = kh; d.kw = kw; d.stride = stride;
+    d.slab = slab; d.grad = grad; d.bias_grad = bias_grad; d.dtype = dtype; d.kh = kh; d.kw = kw; d.stride = stride;
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.OH = OH; d.OW = OW; d.Cout = Cout; d.pad_y = pad_y; d.pad_x = pad_x;
     d.nsplit = srcgan_conv_wgrad_nsplit(B, OH, OW, Cout, Cin, stride);
     d.sr = lay.sr; d.sk = lay.sk; d.sty = lay.sty; d.stx = lay.stx; d.off = lay.off;
@@ -343,8 +344,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     // U0 = fea + trunk_conv(T): d(trunk_conv out) = dU0, d(fea) += dU0 (joined at the end)
     TRef dU0 = S_(Q.dU[0], nf), Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
     if (G(P.p_trunk_w))
-        SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st));
-    if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
+        SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st, G(P.p_trunk_b)));
+    else if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
     SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(dT, H, W, nf).pad(1, 1).run(st));
 
     // ---- RRDB trunk backward.  dcur = gradient w.r.t. the current block output (nf channels).
@@ -367,8 +368,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             const int pbase = P.p_rdb0 + r * 10;
             // conv5
             if (G(pbase + 8))
-                SG_TRY(wgrad_call(dt, dprev, H, W, nf, A, B, H, W, P.C, 3, 3, 1, 1, 1, lay_fwd(P.C, 3, 3), a5, slab, G(pbase + 8), st));
-            if (G(pbase + 9)) SG_TRY(bias_grad(dt, dprev, npix_t, nf, a5, G(pbase + 9), colscr, st));
+                SG_TRY(wgrad_call(dt, dprev, H, W, nf, A, B, H, W, P.C, 3, 3, 1, 1, 1, lay_fwd(P.C, 3, 3), a5, slab, G(pbase + 8), st, G(pbase + 9)));
+            else if (G(pbase + 9)) SG_TRY(bias_grad(dt, dprev, npix_t, nf, a5, G(pbase + 9), colscr, st));
             SG_TRY(Conv(dt, 3, 3, 1).in(dprev, B, H, W, nf).w(wp + P.w_rdb_d[r * 5 + 4]).out(Gd, H, W, P.C).pad(1, 1)
                        .alpha(a5).res1(dprev, nf, bres).mask(A, nf + 3 * gc).run(st));
             // conv4 .. conv1
@@ -376,8 +377,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                 const int cin = nf + k * gc;
                 TRef dyk = sl(Gd, cin);               // gradient of x_{k+1} (already multiplied by LeakyReLU')
                 if (G(pbase + 2 * k))
-                    SG_TRY(wgrad_call(dt, dyk, H, W, gc, A, B, H, W, cin, 3, 3, 1, 1, 1, lay_fwd(cin, 3, 3), 1.f, slab, G(pbase + 2 * k), st));
-                if (G(pbase + 2 * k + 1)) SG_TRY(bias_grad(dt, dyk, npix_t, gc, 1.f, G(pbase + 2 * k + 1), colscr, st));
+                    SG_TRY(wgrad_call(dt, dyk, H, W, gc, A, B, H, W, cin, 3, 3, 1, 1, 1, lay_fwd(cin, 3, 3), 1.f, slab, G(pbase + 2 * k), st, G(pbase + 2 * k + 1)));
+                else if (G(pbase + 2 * k + 1)) SG_TRY(bias_grad(dt, dyk, npix_t, gc, 1.f, G(pbase + 2 * k + 1), colscr, st));
                 Conv cv(dt, 3, 3, 1);
                 cv.in(dyk, B, H, W, gc).w(wp + P.w_rdb_d[r * 5 + k]).out(Gd, H, W, cin).pad(1, 1).res1(Gd, cin, 1.f);
                 if (k > 0) cv.mask(A, cin - gc);
@@ -398,8 +399,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         const int hi = c->H >> s, wi = c->W >> s, ho = hi / 2, wo = wi / 2;
         TRef xin_s = s == 0 ? T_(P.fea0, nf) : T_(P.dn[s - 1], nf);
         const int pw = P.p_dn0 + 2 * s;
-        if (G(pw)) SG_TRY(wgrad_call(dt, dfea, ho, wo, nf, xin_s, B, hi, wi, nf, 3, 3, 2, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(pw), st));
-        if (G(pw + 1)) SG_TRY(bias_grad(dt, dfea, (long)B * ho * wo, nf, 1.f, G(pw + 1), colscr, st));
+        if (G(pw)) SG_TRY(wgrad_call(dt, dfea, ho, wo, nf, xin_s, B, hi, wi, nf, 3, 3, 2, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(pw), st, G(pw + 1)));
+        else if (G(pw + 1)) SG_TRY(bias_grad(dt, dfea, (long)B * ho * wo, nf, 1.f, G(pw + 1), colscr, st));
         TRef dst = S_(Q.dfea_dn[s], nf);
         for (int q = 0; q < 4; ++q) {           // dgrad by output parity (a,b): sub-kernel of 1 or 2 taps per axis
             const int a = q >> 1, bb = q & 1;
@@ -414,8 +415,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     // conv_first
     TRef xin = T_(P.xin, P.in_cs);
     if (G(P.p_first_w))
-        SG_TRY(wgrad_call(dt, dfea, c->H, c->W, nf, xin, B, c->H, c->W, c->in_ch, 3, 3, 1, 1, 1, lay_fwd(c->in_ch, 3, 3), 1.f, slab, G(P.p_first_w), st));
-    if (G(P.p_first_b)) SG_TRY(bias_grad(dt, dfea, (long)B * c->H * c->W, nf, 1.f, G(P.p_first_b), colscr, st));
+        SG_TRY(wgrad_call(dt, dfea, c->H, c->W, nf, xin, B, c->H, c->W, c->in_ch, 3, 3, 1, 1, 1, lay_fwd(c->in_ch, 3, 3), 1.f, slab, G(P.p_first_w), st, G(P.p_first_b)));
+    else if (G(P.p_first_b)) SG_TRY(bias_grad(dt, dfea, (long)B * c->H * c->W, nf, 1.f, G(P.p_first_b), colscr, st));
     if (dx_nchw) {
         TRef dxin = S_(Q.dxin, P.in_cs);
         SG_HIP(hipMemsetAsync(dxin.p, 0, (size_t)B * c->H * c->W * P.in_cs * P.esz, (hipStream_t)st));

@@ -1,0 +1,124 @@
+"""Data-parallel replicas: one process per GPU, torch.distributed ('nccl' == RCCL over xGMI on ROCm;
+'gloo' for the CPU tests).  The reference has no distributed code at all;
+this is the build's addition: parameter broadcast at start (C1) and bucketed, asynchronous gradient
+all-reduce (C2) that the optimiser step waits on.
+
+Images are independent units, so the hot path shards with no data-path collective; the only exchange
+is the gradient mean.  Buckets are flattened into one contiguous buffer each (few, large collectives:
+xGMI is point-to-point, ring steps are per-link bound) and reduced on a side stream so the copy-in of
+bucket k+1 overlaps the collective of bucket k; BatchNorm statistics stay per replica (no SyncBN),
+as single-device reference semantics imply.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["init_from_env", "broadcast_module", "GradSync", "shard_range"]
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, local_rank, world).  world == 1 -> no process group is created."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(n_units: int, rank: int, world: int):
+    """Contiguous [begin, end) share of n independent units (images) for this rank."""
+    base, rem = divmod(n_units, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+@torch.no_grad()
+def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
+    """Make every replica identical to rank `src` (parameters and buffers), one flat message per dtype."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class GradSync:
+    """Mean of parameter gradients across replicas.  ``allreduce(params)`` flattens the existing ``.grad``s
+    into <= bucket_mb buckets (reverse parameter order: the gradients produced first by backward go first),
+    launches every all-reduce asynchronously and writes the averaged values back before returning the
+    stream to the optimiser.  Parameters without a gradient (frozen discriminator, train.py:330) are skipped."""
+
+    def __init__(self, bucket_mb: float = 32.0, group=None):
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._side = torch.cuda.Stream() if torch.cuda.is_available() and self.world > 1 else None
+
+    def _buckets(self, grads: List[torch.Tensor]) -> List[List[torch.Tensor]]:
+        out, cur, size = [], [], 0
+        for g in grads:
+            nb = g.numel() * g.element_size()
+            if cur and size + nb > self.bucket_bytes:
+                out.append(cur)
+                cur, size = [], 0
+            cur.append(g)
+            size += nb
+        if cur:
+            out.append(cur)
+        return out
+
+    @torch.no_grad()
+    def allreduce(self, params: Iterable[torch.nn.Parameter]) -> None:
+        if self.world == 1:
+            return
+        grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
+        if not grads:
+            return
+        inv = 1.0 / self.world
+        cuda = grads[0].is_cuda
+        if cuda:
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            ctx = torch.cuda.stream(self._side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        pending = []
+        with ctx:
+            for bucket in self._buckets(grads):
+                flat = torch.cat([g.reshape(-1) for g in bucket])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                pending.append((work, flat, bucket))
+            for work, flat, bucket in pending:
+                work.wait()
+                off = 0
+                for g in bucket:
+                    n = g.numel()
+                    g.copy_(flat[off:off + n].view_as(g)).mul_(inv)
+                    off += n
+        if cuda:
+            main.wait_stream(self._side)
+            for _, flat, _ in pending:
+                flat.record_stream(main)

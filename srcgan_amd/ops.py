@@ -93,7 +93,8 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, *, kh: int, kw: int, stride: int = 1, Cout: int, Cin: int,
                dy_coff: int = 0, x_coff: int = 0, pad: Tuple[int, int] = (0, 0), layout: Tuple[int, int, int, int, int],
-               alpha: float = 1.0, nsplit: Optional[int] = None, accumulate: bool = False) -> torch.Tensor:
+               alpha: float = 1.0, nsplit: Optional[int] = None, accumulate: bool = False,
+               bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy [B,OH,OW,cs], x [B,H,W,cs] NHWC; grad: canonical f32 tensor written through (sr,sk,sty,stx,off)."""
     N.require_cuda(x, "conv_wgrad")
     lib = N.lib()
@@ -103,6 +104,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, *, kh: int
     ns = nsplit or lib.srcgan_conv_wgrad_nsplit(B, OH, OW, Cout, Cin, stride)
     slab = torch.empty(lib.srcgan_conv_wgrad_slab_bytes(Cout, Cin, kh, kw, ns), dtype=torch.uint8, device=x.device)
     d.dy, d.x, d.slab, d.grad = dy.data_ptr(), x.data_ptr(), slab.data_ptr(), grad.data_ptr()
+    d.bias_grad = bias_grad.data_ptr() if bias_grad is not None else None
     d.dtype = N.dtype_id(x.dtype)
     d.kh, d.kw, d.stride = kh, kw, stride
     d.B, d.H, d.W, d.Cin, d.x_cs, d.x_coff = B, H, W, Cin, xcs, x_coff

@@ -35,3 +35,10 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def rel_l2(a, b):
+    """||a-b|| / ||b|| -- used for the bf16 perf mode, where single elements carry 8-bit rounding noise."""
+    a = torch.as_tensor(a).detach().to(torch.float64).cpu()
+    b = torch.as_tensor(b).detach().to(torch.float64).cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

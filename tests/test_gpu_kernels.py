@@ -146,10 +146,13 @@ def test_dgrad_and_wgrad(ops, dt, cin, cout, k, s, hw):
             ops.conv_igemm(dyd, wp, dx, kh=kh_, kw=kw_, Cout=cin, OH=(H - a + 1) // 2, OW=(W - b + 1) // 2, pad=pad, os=2, oa=a, ob=b)
     assert rel_err(ops.to_nchw(dx).cpu(), xq.grad) < TOL[dt]
     gw = torch.zeros(cout, cin, k, k, device="cuda")
+    gb = torch.zeros(cout, device="cuda") if k == 3 else None       # bias gradient fused into the 3x3 wgrad kernel
     ops.conv_wgrad(dyd, _nhwc(ops, x.detach(), cin, dt), gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(1, 1),
-                   layout=(cin * k * k, k * k, k, 1, 0))
+                   layout=(cin * k * k, k * k, k, 1, 0), bias_grad=gb)
     assert rel_err(gw.cpu(), wq.grad) < TOL[dt]
     assert rel_err(ops.col_sum(dyd, cout).cpu(), dy.sum((0, 2, 3))) < TOL[dt]
+    if gb is not None:
+        assert rel_err(gb.cpu(), dy.sum((0, 2, 3))) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import load_golden, sub, rel_err
+from conftest import load_golden, sub, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -64,7 +64,7 @@ def test_rdb_full_width_golden_f32():
     assert rel_err(ops.to_nchw(out).cpu(), g["y"]) < F32_TOL
 
 
-@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 5e-2)])
 def test_rddbnet_full_width_vs_oracle(dt, tol):
     """nf=64, gc=32, nb=2, x4 on an odd-sized input; forward, input grad and every parameter grad."""
     from srcgan_amd import RDDBNet
@@ -81,9 +81,10 @@ def test_rddbnet_full_width_vs_oracle(dt, tol):
     y = net(xg)
     from srcgan_amd import L1Loss
     L1Loss()(y, t.cuda()).backward()
-    assert rel_err(y.cpu(), yr) < tol
-    assert rel_err(xg.grad.cpu(), xr.grad) < tol * 2
-    worst = max(rel_err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+    err = rel_err if dt == "fp32" else rel_l2     # bf16: relative L2 (8-bit mantissa noise per element)
+    assert err(y.cpu(), yr) < tol
+    assert err(xg.grad.cpu(), xr.grad) < tol * 2
+    worst = max(err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
     assert worst < tol * 2, worst
 
 
@@ -113,9 +114,11 @@ def test_nlayerd_golden_f32(tag):
         assert rel_err(net(x.detach()).cpu(), g["y_eval"]) < F32_TOL
 
 
-@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 8e-2)])
 def test_nlayerd_full_width_vs_oracle(dt, tol):
-    """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch, incl. a frozen pass (dgrad only)."""
+    """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch, incl. a frozen pass (dgrad only).
+    bf16 bound is loose on purpose: with a constant lsgan label the incoming gradient is nearly uniform per channel,
+    so BatchNorm backward (g - mean g - xhat * mean(g xhat)) cancels most of a bf16-rounded g (f32 mode: 4e-6)."""
     from srcgan_amd import NLayerDiscriminator, GANLoss
     sd = oracle.nlayer_d_state(3, 64, 3, seed=5)
     net = _load(NLayerDiscriminator(3, 64, 3, dtype=dt), sd)
@@ -128,9 +131,10 @@ def test_nlayerd_full_width_vs_oracle(dt, tol):
     xg = x.cuda().requires_grad_(True)
     y = net(xg)
     GANLoss("lsgan", device="cuda")(y, False).backward()
-    assert rel_err(y.cpu(), yr) < tol
-    assert rel_err(xg.grad.cpu(), xr.grad) < tol * 2
-    worst = max(rel_err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+    err = rel_err if dt == "fp32" else rel_l2     # bf16: relative L2 (8-bit mantissa noise per element)
+    assert err(y.cpu(), yr) < tol
+    assert err(xg.grad.cpu(), xr.grad) < tol * 2
+    worst = max(err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
     assert worst < tol * 2, worst
     # frozen discriminator (train.py:330): no parameter grads, input grad still flows
     for p in net.parameters():
