@@ -58,6 +58,12 @@ int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, in
 size_t srcgan_packed_weight_bytes(int rows, int kdim, int ntaps, int dtype);
 int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, int tys, int txs,
                        long sr, long sk, long sty, long stx, long off, int dtype, void* stream);
+/* Fill only the k-range [k_off, k_off+kdim) of a packed matrix whose full K is k_total, values scaled by
+ * `scale` (the caller zeroes the buffer first).  Used to assemble the composite transposed weights of the
+ * dense-block backward: K = [conv5 co | conv4 co | ...] for one input-channel slice. */
+int srcgan_pack_weight_part(const float* w, void* wp, int rows, int kdim, int tys, int txs,
+                            long sr, long sk, long sty, long stx, long off, int k_off, int k_total, float scale,
+                            int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Implicit-GEMM convolution (forward form).  Replaces aten::convolution for

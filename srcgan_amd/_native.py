@@ -86,6 +86,7 @@ SIGNATURES = {
     "srcgan_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
     "srcgan_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _P]),
+    "srcgan_pack_weight_part": (_I, [_P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _I, _F, _I, _P]),
     "srcgan_conv_igemm": (_I, [C.POINTER(ConvDesc), _P]),
     "srcgan_conv_wgrad_slab_bytes": (_S, [_I, _I, _I, _I, _I]),
     "srcgan_conv_wgrad_nsplit": (_I, [_I, _I, _I, _I, _I, _I]),

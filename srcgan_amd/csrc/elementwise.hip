@@ -148,13 +148,17 @@ extern "C" int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C
 }
 
 // --------------------------------------------------------------------------- weight packing
-// Wp[rt][chunk][tap][row (COT)][k (KCE)], zero padded.  COT = rows<=32 ? 32 : 64 (must match conv_igemm).
+// Wp[rt][chunk][tap][row (COT)][k (KCE)].  COT = rows<=32 ? 32 : 64 (must match conv_igemm).
+// A call fills the k-range [k_off, k_off+kdim) of rows [0,rows) of a packed matrix whose full K is k_total
+// (composite matrices -- the dense-block backward -- are assembled by several calls); with k_off == 0 &&
+// kdim == k_total the whole padded buffer is written (zero padding included).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_k(const float* __restrict__ w, T* __restrict__ wp, int rows, int kdim,
                                                      int tys, int txs, long sr, long sk, long sty, long stx, long off,
-                                                     int cot, int nchunk, long total) {
+                                                     int cot, int nchunk, long total, int k_off, int k_total, float scale) {
     constexpr int KCE = DT<T>::KCE;
     const int ntap = tys * txs;
+    const bool whole = (k_off == 0 && kdim == k_total);
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         long q = e;
         const int kl = (int)(q % KCE); q /= KCE;
@@ -162,10 +166,10 @@ __global__ __launch_bounds__(256) void pack_weight_k(const float* __restrict__ w
         const int tap = (int)(q % ntap); q /= ntap;
         const int ch = (int)(q % nchunk);
         const int rt = (int)(q / nchunk);
-        const int row = rt * cot + rl, k = ch * KCE + kl;
-        float v = 0.f;
-        if (row < rows && k < kdim) v = w[off + row * sr + k * sk + (tap / txs) * sty + (tap % txs) * stx];
-        wp[e] = from_f<T>(v);
+        const int row = rt * cot + rl, kk = ch * KCE + kl - k_off;
+        const bool in = row < rows && kk >= 0 && kk < kdim;
+        if (in) wp[e] = from_f<T>(scale * w[off + row * sr + kk * sk + (tap / txs) * sty + (tap % txs) * stx]);
+        else if (whole) wp[e] = from_f<T>(0.f);
     }
 }
 
@@ -175,16 +179,24 @@ extern "C" size_t srcgan_packed_weight_bytes(int rows, int kdim, int ntaps, int 
     return (size_t)cdiv(rows, cot) * cdiv(kdim, kce) * ntaps * cot * 64;
 }
 
-extern "C" int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, int tys, int txs,
-                                  long sr, long sk, long sty, long stx, long off, int dtype, void* stream) {
+extern "C" int srcgan_pack_weight_part(const float* w, void* wp, int rows, int kdim, int tys, int txs,
+                                       long sr, long sk, long sty, long stx, long off, int k_off, int k_total, float scale,
+                                       int dtype, void* stream) {
     SG_REQUIRE(w && wp && rows > 0 && kdim > 0 && tys > 0 && txs > 0, "srcgan_pack_weight: bad arguments");
+    SG_REQUIRE(k_off >= 0 && k_off + kdim <= k_total, "srcgan_pack_weight: k range [%d,%d) exceeds k_total %d", k_off, k_off + kdim, k_total);
     const int esz = dtype == SRCGAN_F32 ? 4 : 2, kce = 64 / esz;
-    const int cot = rows <= 32 ? 32 : 64, nchunk = cdiv(kdim, kce);
+    const int cot = rows <= 32 ? 32 : 64, nchunk = cdiv(k_total, kce);
     const long total = (long)cdiv(rows, cot) * nchunk * tys * txs * cot * kce;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weight_k<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream,
-                                             w, (T*)wp, rows, kdim, tys, txs, sr, sk, sty, stx, off, cot, nchunk, total));
+                                             w, (T*)wp, rows, kdim, tys, txs, sr, sk, sty, stx, off, cot, nchunk, total,
+                                             k_off, k_total, scale));
     SG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, int tys, int txs,
+                                  long sr, long sk, long sty, long stx, long off, int dtype, void* stream) {
+    return srcgan_pack_weight_part(w, wp, rows, kdim, tys, txs, sr, sk, sty, stx, off, 0, kdim, 1.f, dtype, stream);
 }
 
 // --------------------------------------------------------------------------- column reductions

@@ -86,6 +86,7 @@ struct RddbPlan {
     int in_cs, out_cs;
     int nparams;
     size_t xin, fea0, dn[5], A, szA, T, U[6], out, wpk, total;
+    size_t w_rdb_d0, w_rdb_dsz;                    // contiguous region of the composite dense-block dgrad packs
     // packed weights (offsets relative to wpk): per conv
     size_t w_first_f, w_first_d, w_trunk_f, w_trunk_d, w_last_f, w_last_d;
     std::vector<size_t> w_rdb_f, w_rdb_d;          // [nb*15]
@@ -135,11 +136,16 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
         for (int k = 0; k < 5; ++k) {
             const int cin = c->nf + k * c->gc, cout = k < 4 ? c->gc : c->nf;
             P.w_rdb_f[i * 5 + k] = pk(cout, cin, 9);
-            P.w_rdb_d[i * 5 + k] = pk(cin, cout, 9);
         }
     P.w_trunk_f = pk(c->nf, c->nf, 9); P.w_trunk_d = pk(c->nf, c->nf, 9);
     for (int s = 0; s < P.nst; ++s) { for (int q = 0; q < 4; ++q) P.w_up_f[s][q] = pk(c->nf, c->nf, 1); P.w_up_d[s] = pk(c->nf, c->nf, 4); }
     P.w_last_f = pk(c->out_ch, c->nf, 9); P.w_last_d = pk(c->nf, P.out_cs, 9);
+    // dense-block backward: slice j of the block input gets its gradient from ONE conv over the concatenated
+    // output-gradients [dy5 | dy4 | ... | dy_{j+1}] (rows = slice channels, K = nf + (4-j)*gc)
+    P.w_rdb_d0 = wb.off;
+    for (int i = 0; i < c->nb * 3; ++i)
+        for (int j = 0; j < 5; ++j) P.w_rdb_d[i * 5 + j] = pk(j == 0 ? c->nf : c->gc, c->nf + (4 - j) * c->gc, 9);
+    P.w_rdb_dsz = wb.off - P.w_rdb_d0;
     P.total = align_up(P.wpk + wb.off + 256, 256);
     // parameter indices (state_dict order)
     int n = 0;
@@ -297,12 +303,19 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         for (int s = 0; s < P.nst; ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
             SG_TRY(srcgan_pack_weight(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0, dt, st));
         SG_TRY(srcgan_pack_weight(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off, dt, st));
-        for (int i = 0; i < c->nb * 3; ++i)
-            for (int k = 0; k < 5; ++k) {
-                const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
-                const WLayout Lk = lay_dgrad_s1(cin, 3, 3);
-                SG_TRY(srcgan_pack_weight(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_d[i * 5 + k], cin, cout, 3, 3, Lk.sr, Lk.sk, Lk.sty, Lk.stx, Lk.off, dt, st));
+        SG_HIP(hipMemsetAsync(wp + P.w_rdb_d0, 0, P.w_rdb_dsz, (hipStream_t)st));
+        for (int r = 0; r < c->nb * 3; ++r) {
+            const float a5 = (r % 3 == 2) ? 0.04f : 0.2f;       // d(x5)/d(block out), RDB3 carries the RRDB 0.2 too
+            for (int j = 0; j < 5; ++j) {
+                const int rows = j == 0 ? nf : gc, ss = j == 0 ? 0 : nf + (j - 1) * gc, ktot = nf + (4 - j) * gc;
+                for (int m = 5; m > j; --m) {                   // block of K coming from forward conv m
+                    const int cin_m = nf + (m - 1) * gc, cout_m = m == 5 ? nf : gc;
+                    const int k_off = m == 5 ? 0 : nf + (4 - m) * gc;
+                    SG_TRY(srcgan_pack_weight_part(params[P.p_rdb0 + (r * 5 + m - 1) * 2], wp + P.w_rdb_d[r * 5 + j], rows, cout_m, 3, 3,
+                                                   9, (long)cin_m * 9, -3, -1, (long)ss * 9 + 8, k_off, ktot, m == 5 ? a5 : 1.f, dt, st));
+                }
             }
+        }
         for (int s = 0; s < P.ndn; ++s)
             for (int q = 0; q < 4; ++q) {
                 // 3x3 s2 p1 dgrad, output parity (a,b): rows with ky = a+1 (mod 2).  a=0: ky=1 (1 tap); a=1: ky=2,0 (2 taps)
@@ -346,49 +359,46 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     if (G(P.p_trunk_w))
         SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st, G(P.p_trunk_b)));
     else if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
-    SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(dT, H, W, nf).pad(1, 1).run(st));
-
-    // ---- RRDB trunk backward.  dcur = gradient w.r.t. the current block output (nf channels).
-    TRef dcur = dT;
-    int dcur_buf = -1;       // which of the 3 rotating dense-grad buffers holds dcur (-1: dT)
+    // Dense gradient buffers (3, rotating): Gd = [dy5 (nf) | dy4 | dy3 | dy2 | dy1] -- the mirror image of the forward
+    // dense buffer.  Slice j of the block input gets its gradient from ONE conv over the channel prefix holding
+    // dy5..dy_{j+1} (composite transposed weights), so every gradient element is written exactly once: no
+    // read-modify-write accumulation, and the same prefix-read / slice-write pattern as forward.
+    auto Pg = [&](int g) { return tref(s8 + Q.Pg[g], P.C); };
+    SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(Pg(0), H, W, nf).pad(1, 1).run(st));
+    (void)dT;
     for (int i = c->nb - 1; i >= 0; --i) {
-        const TRef d_rrdb = dcur;
-        const int rrdb_buf = dcur_buf;
-        TRef dprev = d_rrdb;       // dOut of the RDB being processed
-        int prev_buf = rrdb_buf;
-        for (int j = 2; j >= 0; --j) {
-            const int r = i * 3 + j;
-            TRef A = Abuf(r);
-            int gb = 0;
-            while (gb == rrdb_buf || gb == prev_buf) ++gb;
-            TRef Gd = tref(s8 + Q.Pg[gb], P.C);
-            // scale of d(x5) relative to dprev, and of the block-input residual
-            const float a5 = (j == 2) ? 0.04f : 0.2f;
-            const float bres = (j == 2) ? 0.2f : 1.f;
+        for (int j3 = 2; j3 >= 0; --j3) {                  // RDB3, RDB2, RDB1 use Pg(0), Pg(1), Pg(2)
+            const int r = i * 3 + j3, g = 2 - j3;
+            TRef A = Abuf(r), Gd = Pg(g), nxt = Pg((g + 1) % 3);
+            const float a5 = (j3 == 2) ? 0.04f : 0.2f;     // folded into the packed conv5 block; wgrad/bias use it as alpha
+            const float bres = (j3 == 2) ? 0.2f : 1.f;     // block-input residual: d(in) += bres * d(out)
             const int pbase = P.p_rdb0 + r * 10;
-            // conv5
-            if (G(pbase + 8))
-                SG_TRY(wgrad_call(dt, dprev, H, W, nf, A, B, H, W, P.C, 3, 3, 1, 1, 1, lay_fwd(P.C, 3, 3), a5, slab, G(pbase + 8), st, G(pbase + 9)));
-            else if (G(pbase + 9)) SG_TRY(bias_grad(dt, dprev, npix_t, nf, a5, G(pbase + 9), colscr, st));
-            SG_TRY(Conv(dt, 3, 3, 1).in(dprev, B, H, W, nf).w(wp + P.w_rdb_d[r * 5 + 4]).out(Gd, H, W, P.C).pad(1, 1)
-                       .alpha(a5).res1(dprev, nf, bres).mask(A, nf + 3 * gc).run(st));
-            // conv4 .. conv1
-            for (int k = 3; k >= 0; --k) {
-                const int cin = nf + k * gc;
-                TRef dyk = sl(Gd, cin);               // gradient of x_{k+1} (already multiplied by LeakyReLU')
-                if (G(pbase + 2 * k))
-                    SG_TRY(wgrad_call(dt, dyk, H, W, gc, A, B, H, W, cin, 3, 3, 1, 1, 1, lay_fwd(cin, 3, 3), 1.f, slab, G(pbase + 2 * k), st, G(pbase + 2 * k + 1)));
-                else if (G(pbase + 2 * k + 1)) SG_TRY(bias_grad(dt, dyk, npix_t, gc, 1.f, G(pbase + 2 * k + 1), colscr, st));
+            for (int m = 5; m >= 1; --m) {
+                // dy_m is final here: weight/bias gradient of forward conv m
+                const int cin_m = nf + (m - 1) * gc, cout_m = m == 5 ? nf : gc;
+                TRef dym = sl(Gd, m == 5 ? 0 : nf + (4 - m) * gc);
+                const float am = m == 5 ? a5 : 1.f;
+                if (G(pbase + 2 * (m - 1)))
+                    SG_TRY(wgrad_call(dt, dym, H, W, cout_m, A, B, H, W, cin_m, 3, 3, 1, 1, 1, lay_fwd(cin_m, 3, 3), am, slab,
+                                      G(pbase + 2 * (m - 1)), st, G(pbase + 2 * (m - 1) + 1)));
+                else if (G(pbase + 2 * (m - 1) + 1))
+                    SG_TRY(bias_grad(dt, dym, npix_t, cout_m, am, G(pbase + 2 * (m - 1) + 1), colscr, st));
+                // gradient of input slice j = m-1 from [dy5 .. dy_m]
+                const int j = m - 1, ktot = nf + (4 - j) * gc;
                 Conv cv(dt, 3, 3, 1);
-                cv.in(dyk, B, H, W, gc).w(wp + P.w_rdb_d[r * 5 + k]).out(Gd, H, W, cin).pad(1, 1).res1(Gd, cin, 1.f);
-                if (k > 0) cv.mask(A, cin - gc);
-                else if (j == 0) cv.res2(d_rrdb, nf, 1.f);      // RRDB skip: d(x_rrdb) += d(out_rrdb)
+                cv.in(Gd, B, H, W, ktot).w(wp + P.w_rdb_d[r * 5 + j]).pad(1, 1);
+                if (j > 0) {
+                    // slice x_j is a LeakyReLU output: multiply by its derivative -> this IS dy_j
+                    cv.out(sl(Gd, nf + (4 - j) * gc), H, W, gc).mask(sl(A, nf + (j - 1) * gc), 0);
+                } else {
+                    cv.out(nxt, H, W, nf).res1(Gd, nf, bres);
+                    if (j3 == 0) cv.res2(nxt, nf, 1.f);     // RRDB skip; nxt == Pg(0) still holds d(out_rrdb): in-place, same element
+                }
                 SG_TRY(cv.run(st));
             }
-            dprev = Gd; prev_buf = gb;
         }
-        dcur = dprev; dcur_buf = prev_buf;
     }
+    TRef dcur = Pg(0);
     // gradient w.r.t. the trunk input feature = dcur + dU0 (global skip); for the HR->LR variant the trunk input
     // is a LeakyReLU output, so its derivative is applied in the same pass.
     TRef trunk_in = Abuf(0);
