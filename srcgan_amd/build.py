@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcgan_amd.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "elementwise.hip", "nets.hip"]
+SOURCES = ["conv_igemm.hip", "conv3x3_dma.hip", "conv_wgrad.hip", "elementwise.hip", "nets.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -30,7 +30,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "srcgan_amd.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(HERE, "..", "include", "srcgan_amd.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

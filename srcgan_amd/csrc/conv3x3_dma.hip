@@ -1,0 +1,246 @@
+// 3x3 stride-1 convolution, the hot kernel of the RRDB trunk (reference src/model/rddb.py:52-58, 345 of
+// them per 23-block generator pass, and -- with transposed packs -- all of their dgrads).
+//
+// Differences from the generic conv_igemm kernel, all aimed at the LDS bottleneck its profile showed
+// (LDS array ~80 % busy: ds_write_b128 staging costs 13 cycles/instruction, 3x a read):
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): no VGPR staging,
+//     no ds_write, ~4 LDS cycles per KiB.
+//   * the LDS image is UNPADDED (64 B per pixel / per weight row) and XOR-swizzled: 16-byte slot s of
+//     pixel p holds channel-part s ^ ((p >> 2) & 3).  LDS-DMA writes lane-linear, so the swizzle is applied
+//     to each lane's global SOURCE address and again on the ds_read_b128 address (both sides or neither).
+//     Any 16 consecutive pixels then cover all 16 slots of the 256-B bank row: conflict-free.
+//   * one workgroup of 8 waves (2 per SIMD) per CU works on a 16x32-pixel tile with double-buffered
+//     LDS: the DMA of chunk c+1 is in flight during the MFMAs of chunk c; one barrier per chunk.
+//     (tile twice as large as the generic kernel -> weight traffic per FLOP halves.)
+//   * out-of-image / past-Cin pieces are fetched from a 64-byte zero page instead of being branched on.
+#include "conv_params.h"
+#include <type_traits>
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(64))) unsigned int sg_zero_page[16];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int MT, int NWV, int NBUF, int PT>
+__global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
+    using D = DT<T>;
+    static_assert(NBUF == 2, "persistent pipeline is double-buffered");
+    constexpr int TH = PT * NWV, TW = 32, IHT = TH + 2, IWT = TW + 2;
+    constexpr int COT = 32 * MT, NTAP = 9;
+    constexpr int NHP = IHT * IWT;                       // halo pixels
+    constexpr int HPIECES = (NHP * 64 + 1023) / 1024;    // one-KiB DMA pieces (last one partly junk)
+    constexpr int WPIECES = NTAP * COT * 64 / 1024;      // 36 (MT=2) / 18 (MT=1)
+    constexpr int HBYTES = HPIECES * 1024, WBYTES = WPIECES * 1024, SBYTES = HBYTES + WBYTES;
+    constexpr int HIT = (HPIECES + NWV - 1) / NWV, WIT = (WPIECES + NWV - 1) / NWV;
+    constexpr int ERS = COT * 4 + 16;                    // epilogue transpose row stride
+    static_assert(NWV * 32 * ERS <= SBYTES, "epilogue transpose space must fit one stage");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];    // [stage0: halo | weights][stage1: halo | weights]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    // Persistent workgroups.  Units (spatial tile x Cout tile) are dealt so that the workgroups of one XCD
+    // (blockIdx % 8) walk one contiguous range together: neighbouring halos / the Cout tiles of a tile share an L2.
+    const int nunits = p.tiles_x * p.tiles_y * p.B * p.ctiles;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, gw = (gridDim.x + 7 - xcd) >> 3;   // my index / #WGs in my XCD group
+    const int u8 = (nunits + 7) >> 3;
+    const int u_lo = xcd * u8, u_hi = (u_lo + u8 < nunits) ? u_lo + u8 : nunits;
+
+    const char* zp = (const char*)sg_zero_page;
+    const int wsw = (r >> 2) & 3;
+
+    // ---- DMA descriptors of the unit being fetched.  Piece pi (1 KiB) = LDS slots [pi*64, pi*64+64); slot q -> pixel
+    // q>>2, physical part q&3, which holds logical channel-part (q&3) ^ ((pixel>>2)&3).
+    int h_goff[HIT], h_part[HIT], w_off[WIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int q = (it * NWV + wave) * 64 + lane, lp = q >> 2;
+        h_part[it] = (q & 3) ^ ((lp >> 2) & 3);
+    }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int q = (it * NWV + wave) * 64 + lane, wr = q >> 2;
+        w_off[it] = wr * 64 + (((q & 3) ^ ((wr >> 2) & 3)) * 16);
+    }
+    const char* f_xb = nullptr; const char* f_wb = nullptr;      // fetch-side base pointers
+    auto setup_fetch = [&](int u, int& ob, int& oct, int& ooy0, int& oox0) {
+        const int ct = u % p.ctiles; int t = u / p.ctiles;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+        ob = b; oct = ct; ooy0 = ty * TH; oox0 = tx * TW;
+        const int gy0 = ooy0 - p.pad_y, gx0 = oox0 - p.pad_x;
+        f_xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+        f_wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int q = (it * NWV + wave) * 64 + lane, lp = q >> 2;
+            const int iy = lp / IWT, ix = lp - iy * IWT;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool ok = lp < NHP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            h_goff[it] = ok ? ((gy * p.W + gx) * p.xCs * (int)sizeof(T) + h_part[it] * 16) : -1;
+        }
+    };
+    auto issue = [&](int c, int stage) {
+        char* lh = smem + stage * SBYTES;
+        char* lw = lh + HBYTES;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int pi = it * NWV + wave;
+            if (HIT * NWV == HPIECES || pi < HPIECES) {        // wave-uniform
+                const bool ok = h_goff[it] >= 0 && (c * D::KCE + h_part[it] * D::EPP < p.Cin);
+                const char* src = ok ? f_xb + h_goff[it] + c * 64 : zp;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lh + pi * 1024), 16, 0, 0);
+            }
+        }
+        const char* ws = f_wb + (size_t)c * NTAP * COT * 64;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int pi = it * NWV + wave;
+            if (WIT * NWV == WPIECES || pi < WPIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ws + w_off[it]), (lptr_t)(lw + pi * 1024), 16, 0, 0);
+        }
+    };
+
+    int u = u_lo + jw;
+    if (u >= u_hi) return;
+    int cb, cct, coy0, cox0;            // unit being computed
+    int nb_, nct, noy0, nox0;           // unit being fetched
+    setup_fetch(u, nb_, nct, noy0, nox0);
+    issue(0, 0);
+    int stage = 0;
+    for (; u < u_hi; u += gw) {
+        cb = nb_; cct = nct; coy0 = noy0; cox0 = nox0;
+        f32x16 acc[MT][PT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+
+        for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
+            __syncthreads();        // own DMAs into `stage` landed (vmcnt(0)); everyone is done with the other stage
+            if (!(p.dbg & 2)) {
+                if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
+                else if (u + gw < u_hi) { setup_fetch(u + gw, nb_, nct, noy0, nox0); issue(0, stage ^ 1); }   // next unit's first chunk
+            }
+            const char* lh = smem + stage * SBYTES;
+            const char* lw = lh + HBYTES;
+            if (p.dbg & 1) continue;
+            // 18 k-steps (9 taps x 2 halves of the 64-byte chunk), software-pipelined: the fragments of step s+1 are
+            // requested from LDS before the MFMAs of step s issue, so LDS latency hides under the matrix pipe.
+            using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
+            frag_t fa[2][MT], fb[2][PT];
+            auto load_step = [&](int s, frag_t (&a)[MT], frag_t (&bq)[PT]) {
+                const int tap = s >> 1, ks = s & 1, ky = tap / 3, kx = tap - ky * 3;
+                const int kp = ks * 2 + h;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *(const frag_t*)(lw + (tap * COT + m * 32 + r) * 64 + ((kp ^ wsw) * 16));
+#pragma unroll
+                for (int q = 0; q < PT; ++q) {
+                    const int lp = (wave * PT + q + ky) * IWT + r + kx;
+                    bq[q] = *(const frag_t*)(lh + lp * 64 + ((kp ^ ((lp >> 2) & 3)) * 16));
+                }
+            };
+            load_step(0, fa[0], fb[0]);
+            const bool skip_rd = p.dbg & 16, skip_mm = p.dbg & 8;
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18 && !skip_rd) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the next step's ds_reads ahead of this step's MFMAs
+                if (skip_mm) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(fa[s & 1][m]));
+#pragma unroll
+                    for (int q = 0; q < PT; ++q) asm volatile("" :: "v"(fb[s & 1][q]));
+                } else if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int q = 0; q < PT; ++q)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][m][j], fb[s & 1][q][j], acc[m][q], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < PT; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][m], fb[s & 1][q], acc[m][q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.dbg & 4) continue;
+        // ---- epilogue of the finished unit; the next unit's first chunk is already in flight into `stage`
+        // (the loop increment flipped it), so the transpose space is the OTHER stage = the one just computed from.
+        if (p.vec16) {
+            __syncthreads();      // every wave finished reading the last chunk before its stage is reused
+            char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+                conv_epilogue_lds_row<T, MT, PT>(p, acc, q, tsp, cb, cct, coy0 + wave * PT + q, cox0, lane);
+        } else {
+            conv_epilogue<T, MT, PT>(p, acc, cb, cct, coy0 + wave * PT, cox0, r, h);
+        }
+    }
+}
+
+template <typename T, int MT, int NWV, int NBUF, int PT>
+static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
+    constexpr int TH = PT * NWV;
+    constexpr int HB = (((TH + 2) * 34 * 64 + 1023) / 1024) * 1024, WB = 9 * 32 * MT * 64;
+    constexpr size_t SMEM = NBUF * ((size_t)HB + (size_t)WB);
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_dma_k<T, MT, NWV, NBUF, PT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set = true;
+    }
+    ConvP q = p;
+    { static const char* e = getenv("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
+    q.tiles_x = cdiv(p.OW, 32);
+    q.tiles_y = cdiv(p.OH, TH);
+    q.ctiles = ctiles;
+    const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
+    static int wg_per_cu = 0, ncu = 0;
+    if (!wg_per_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        SG_HIP(hipGetDevice(&dev)); SG_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+        wg_per_cu = (int)((160 * 1024) / SMEM); if (wg_per_cu < 1) wg_per_cu = 1;
+        if (wg_per_cu * NWV > 16) wg_per_cu = 16 / NWV;
+    }
+    size_t nwg = (size_t)ncu * wg_per_cu;
+    if (nwg > nunits) nwg = nunits;
+    dim3 grid((unsigned)nwg, 1, 1);
+    char cls[96];
+    snprintf(cls, sizeof(cls), "conv3x3_dma<%s,MT%d,W%d,B%d,PT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NWV, NBUF, PT);
+    const double px = (double)p.B * p.OH * p.OW;
+    const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), SMEM, st, q);
+    sg_prof_stop(tok, st);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int dispatch_dma(const ConvP& p, hipStream_t st) {
+    static const char* cfg_env = getenv("SRCGAN_DMA_CFG");
+    const char cfg = cfg_env ? cfg_env[0] : 'a';
+    if (p.Cout <= 32) {
+        if (cfg == 'b') return launch_dma<T, 1, 4, 2, 2>(p, 1, st);
+        if (cfg == 'd') return launch_dma<T, 1, 4, 2, 4>(p, 1, st);
+        return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
+    }
+    const int ctiles = cdiv(p.Cout, 64);
+    if (cfg == 'b') return launch_dma<T, 2, 4, 2, 2>(p, ctiles, st);
+    if (cfg == 'd') return launch_dma<T, 2, 4, 2, 4>(p, ctiles, st);
+    return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
+}
+
+// entry used by srcgan_conv_igemm for kh == kw == 3, stride 1
+int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st) {
+    return dtype == SRCGAN_F32 ? dispatch_dma<float>(p, st) : dispatch_dma<__bf16>(p, st);
+}

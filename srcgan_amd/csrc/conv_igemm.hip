@@ -17,17 +17,9 @@
 //                                            = 16 f32  (8 x mfma_32x32x2_f32).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
-struct ConvP {
-    const void* x; const void* wp; const float* bias; void* y;
-    const void* r1; const void* r2; const void* mz;
-    int B, H, W, Cin, xCs, xcoff;
-    int OH, OW, Cout, YH, YW, yCs, ycoff;
-    int pad_y, pad_x, os, oa, ob;
-    int r1Cs, r1coff, r1cend, r2Cs, r2coff, r2cend, mzCs, mzcoff, mzc0;
-    float alpha, beta1, beta2, slope, mslope;
-    int act, vec, nchunk, tiles_x, tiles_y, ctiles;
-};
+#include "conv_params.h"
 
 
 template <typename T, int KH, int KW, int S, int MT, int PT, bool WPK>
@@ -195,63 +187,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         __syncthreads();   // all waves are done reading this chunk's LDS image
     }
 
-    // ---- epilogue.  acc[m][q][4g+i] = D[cout = 32m + 8g + 4h + i][pixel = r]
-    const int ox = ox0 + r;
-#pragma unroll
-    for (int q = 0; q < PT; ++q) {
-        const int oy = oy0 + wave * PT + q;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const size_t opix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + (size_t)ox * p.os + p.ob;
-        T* yp = (T*)p.y + opix * p.yCs + p.ycoff;
-        const T* r1p = p.r1 ? (const T*)p.r1 + opix * p.r1Cs + p.r1coff : nullptr;
-        const T* r2p = p.r2 ? (const T*)p.r2 + opix * p.r2Cs + p.r2coff : nullptr;
-        const T* mzp = p.mz ? (const T*)p.mz + opix * p.mzCs + p.mzcoff : nullptr;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co0 = ct * COT + m * 32 + 8 * g + 4 * h;
-                if (co0 >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[m][q][4 * g + i];
-                if (p.vec) {
-                    if (p.bias) { f32x4 bv = *(const f32x4*)(p.bias + co0);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += bv[i]; }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
-                    if (r1p && co0 < p.r1cend) { float rv[4]; load4<T>(r1p + co0, rv);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += p.beta1 * rv[i]; }
-                    if (r2p && co0 < p.r2cend) { float rv[4]; load4<T>(r2p + co0, rv);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += p.beta2 * rv[i]; }
-                    if (p.act) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-                    if (mzp && co0 >= p.mzc0) { float zv[4]; load4<T>(mzp + co0, zv);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] *= (zv[i] > 0.f ? 1.f : p.mslope); }
-                    store4<T>(yp + co0, v);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int co = co0 + i;
-                        if (co >= p.Cout) continue;
-                        float u = v[i];
-                        if (p.bias) u += p.bias[co];
-                        u *= p.alpha;
-                        if (r1p && co < p.r1cend) u += p.beta1 * to_f(r1p[co]);
-                        if (r2p && co < p.r2cend) u += p.beta2 * to_f(r2p[co]);
-                        if (p.act) u = u > 0.f ? u : u * p.slope;
-                        if (mzp && co >= p.mzc0) u *= (to_f(mzp[co]) > 0.f ? 1.f : p.mslope);
-                        yp[co] = from_f<T>(u);
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<T, MT, PT>(p, acc, b, ct, oy0 + wave * PT, ox0, r, h);
 }
 
 // ------------------------------------------------------------------ host launcher
@@ -301,6 +237,9 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
     SG_FAIL("srcgan_conv_igemm: unsupported kernel %dx%d stride %d", kh, kw, s);
 }
 
+int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st);      // conv3x3_dma.hip
+static const bool g_force_generic = getenv("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
+
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     SG_REQUIRE(d && d->x && d->wp && d->y, "srcgan_conv_igemm: null pointer");
     SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_igemm: bad dtype %d", d->dtype);
@@ -333,7 +272,15 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
             (!d->r1 || (m4(d->r1_cs) && m4(d->r1_coff) && m4(d->r1_cend) && (uintptr_t)d->r1 % 16 == 0)) &&
             (!d->r2 || (m4(d->r2_cs) && m4(d->r2_coff) && m4(d->r2_cend) && (uintptr_t)d->r2 % 16 == 0)) &&
             (!d->mz || (m4(d->mz_cs) && m4(d->mz_coff) && m4(d->mz_c0) && (uintptr_t)d->mz % 16 == 0));
+    {
+        auto me = [&](int v) { return v % epp == 0; };
+        p.vec16 = p.vec && me(d->Cout) && me(d->y_cs) && me(d->y_coff) &&
+                  (!d->r1 || (me(d->r1_cs) && me(d->r1_coff) && me(d->r1_cend))) &&
+                  (!d->r2 || (me(d->r2_cs) && me(d->r2_coff) && me(d->r2_cend))) &&
+                  (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
+    }
     hipStream_t st = (hipStream_t)stream;
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && !g_force_generic) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);
