@@ -34,20 +34,68 @@ def mac_d3(H):
     return 3072 * (H // 2) ** 2 + 131072 * (H // 4) ** 2 + 524288 * (H // 8) ** 2 + 2097152 * (H // 8 - 1) ** 2 + 8192 * (H // 8 - 2) ** 2
 
 
-def cpu_baseline(nb, lr_hw, up, threads):
-    """The CPU oracle (restatement of the reference, pinned by golden vectors) timed on this host:
-    ONE paired step on ONE image of the same workload shape (bounded sample)."""
+def host_cores():
+    """CPU cores this process may really use: scheduler affinity, capped by the cgroup CPU quota (a GPU box hands
+    each job a share of a much larger host; torch with one thread per *host* core thrashes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("SRCGAN_BENCH_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(nb, lr_hw, up, threads, crop=256):
+    """The CPU oracle (restatement of the reference, pinned by golden vectors) timed on this host's cores on a
+    BOUNDED sample of the same workload: ONE paired G+D step of the same networks on one crop x crop LR crop
+    (a full 256x256 image is (lr_hw/crop)^2 such crops; every layer is a convolution, so work scales with pixels).
+    value = full-size images/s implied by the crop time."""
     import oracle
     torch.set_num_threads(threads)
+    crop = min(crop, lr_hw)
     st = oracle.make_paired_state(3, 3, up, 64, nb, 32, 64, 3, seed=0)
     g = torch.Generator().manual_seed(1234)
-    x = torch.rand(1, 3, lr_hw, lr_hw, generator=g)
-    y = torch.rand(1, 3, lr_hw * up, lr_hw * up, generator=g)
+    x = torch.rand(1, 3, crop, crop, generator=g)
+    y = torch.rand(1, 3, crop * up, crop * up, generator=g)
+    print(f"[bench] cpu_baseline: 1 paired step on a {crop}x{crop} crop, {threads} threads ...", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     oracle.paired_step(st, x, y)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 paired G+D step, batch 1, 3x{lr_hw}x{lr_hw}->3x{lr_hw*up}x{lr_hw*up}, nb={nb}, fp32 torch CPU oracle, {dt:.1f} s"}
+    frac = (crop / lr_hw) ** 2
+    return {"value": frac / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 paired G+D step of the same networks (nb={nb}) on one 3x{crop}x{crop}->3x{crop*up}x{crop*up} crop "
+                      f"= {frac:.4f} of an image's pixels, fp32 torch CPU oracle, {dt:.1f} s; value = {frac:.4f}/{dt:.1f}s"}
+
+
+def pmc_traffic(cls):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate --pmc runs of this same command: scripts/profile_round.sh).  PMC counters
+    cannot be read from inside the timed process, so this is the last profiled value or null."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    m = re.match(r"(\w+)<(\w+),(.*)>", cls)
+    if not m:
+        return None
+    base, mt = m.group(1), re.search(r"MT(\d)", cls)
+    for name, v in data.items():           # rocprof demangles template arguments inconsistently: match on kernel + MT
+        if base in name and (mt is None or f", {mt.group(1)}, " in name or f"Li{mt.group(1)}E" in name):
+            return v["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -119,7 +167,9 @@ def main():
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             roofline = {"bound": "mfma", "kernel": k["cls"], "launches": k["count"], "avg_ms": k["ms"] / k["count"],
-                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "traffic": pmc_traffic(k["cls"]),
+                        "algorithmic_bytes_per_launch": k["bytes"] / k["count"],
                         "algorithmic_gbytes_per_s": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
     barrier()
 
@@ -143,7 +193,7 @@ def main():
                          "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 1)} for k in kernels[:8]],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.nb, h, args.up, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.nb, h, args.up, host_cores())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -1,0 +1,139 @@
+"""CPU: host-side mirror of the reference interface -- names, constructor signatures, state_dict keys / shapes,
+initialisation statistics, harness bookkeeping.  Nothing here needs (or may silently fall back from) a GPU."""
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import srcgan_amd
+from srcgan_amd import train as T
+from conftest import load_golden, sub
+
+
+def test_exports_reference_names():
+    for name in ("RDDBNet", "RDDBNetA", "NLayerDiscriminator", "L1Loss", "MSELoss", "PSNRLoss", "GANLoss"):
+        assert hasattr(srcgan_amd, name)
+    assert repr(srcgan_amd.L1Loss()) == "L1" and repr(srcgan_amd.MSELoss()) == "MSE" and repr(srcgan_amd.PSNRLoss()) == "PSNR"
+
+
+@pytest.mark.parametrize("tag", ["rddbnet_x2", "rddbnet_x4", "rddbnet_x2_w32"])
+def test_rddbnet_state_dict_matches_reference(tag):
+    g = load_golden(tag)
+    ic, oc, up, nf, nb, gc = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    net = srcgan_amd.RDDBNet(ic, oc, up, nf=nf, nb=nb, gc=gc)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in ref.values()]
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    net.load_state_dict(ref, strict=True)          # reference checkpoints load
+    assert [n for n, _ in net.named_parameters()] == oracle.rddbnet_keys(nb, up)
+
+
+@pytest.mark.parametrize("tag", ["nlayerd_3", "nlayerd_2"])
+def test_nlayerd_state_dict_matches_reference(tag):
+    g = load_golden(tag)
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    net = srcgan_amd.NLayerDiscriminator(ic, ndf, nl)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in ref.values()]
+    net.load_state_dict(ref, strict=True)
+
+
+def test_full_size_parameter_counts():
+    # 16 619 968 params / 697 tensors ; 2 765 633 / 13
+    g = srcgan_amd.RDDBNet(3, 3, 4, nb=23)
+    assert sum(p.numel() for p in g.parameters()) == 16619968 and len(list(g.parameters())) == 697
+    d = srcgan_amd.NLayerDiscriminator(3, 64, 3)
+    assert sum(p.numel() for p in d.parameters()) == 2765633 and len(list(d.parameters())) == 13
+
+
+def test_same_seed_gives_reference_initialisation():
+    """parameter holders are torch modules created in the reference's order, so the same seed reproduces
+    the reference's initial weights (stored in the golden file) exactly."""
+    g = load_golden("rddbnet_x2")
+    torch.manual_seed(0)
+    net = srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8)
+    for k, v in sub(g, "sd/").items():
+        assert torch.equal(net.state_dict()[k], v), k
+
+
+def test_init_statistics():
+    torch.manual_seed(1)
+    net = srcgan_amd.RDDBNet(3, 3, 4, nf=64, nb=1, gc=32)
+    w = net.RRDB_trunk[0].RDB1.conv5.weight          # kaiming normal, fan_out = 64*9
+    assert abs(float(w.std()) - math.sqrt(2.0 / (64 * 9))) < 2e-3
+    dw = net.upscale_layers[0].weight                 # ConvTranspose2d keeps torch's default: U(+-1/sqrt(64*4))
+    assert float(dw.abs().max()) <= 0.0625 + 1e-6 and float(dw.abs().max()) > 0.06
+
+
+def test_no_cpu_fallback_anywhere():
+    x = torch.rand(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8)(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        srcgan_amd.NLayerDiscriminator(3, 16, 2)(torch.rand(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        srcgan_amd.L1Loss()(x, x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        srcgan_amd.GANLoss("lsgan")(x, True)
+
+
+def test_ganloss_modes():
+    g = srcgan_amd.GANLoss("lsgan", device="cpu", target_real_label=0.9)
+    assert float(g.real_label) == pytest.approx(0.9) and float(g.fake_label) == 0.0
+    assert g.get_target_tensor(torch.zeros(2, 1, 3, 3), True).shape == (2, 1, 3, 3)
+    with pytest.raises(NotImplementedError):
+        srcgan_amd.GANLoss("hinge")
+
+
+def test_unsupported_norm_layer_is_rejected():
+    with pytest.raises(NotImplementedError):
+        srcgan_amd.NLayerDiscriminator(3, 64, 3, norm_layer=torch.nn.InstanceNorm2d)
+
+
+def test_image_pool_matches_oracle():
+    a, b = random.Random(3), random.Random(3)
+    mine, ref = T.ImagePool(4, a), oracle.ImagePoolOracle(4, b)
+    torch.manual_seed(0)
+    for _ in range(12):
+        batch = torch.rand(2, 3, 4, 4)
+        assert torch.equal(mine.query(batch), ref.query(batch))
+    assert torch.equal(T.ImagePool(0).query(batch), batch)
+
+
+def test_cas_lr_schedule_matches_reference():
+    g = load_golden("cas_step")
+    seq = oracle.cosine_lr_sequence(1e-4, 3, 50)
+    assert seq[0] == pytest.approx(float(g["lr_after"]), rel=1e-9)     # measured on the reference CasSRC.update_lr
+
+    class Dummy(T.CasSRC):
+        def __init__(self):
+            p = [torch.nn.Parameter(torch.zeros(1))]
+            self.optimizers = [torch.optim.Adam(p, lr=1e-4), torch.optim.Adam(p, lr=1e-4)]
+    m, opt = Dummy(), T.CasParams(device="cpu")
+    for e in range(3):
+        m.update_lr(opt)
+        assert m.optimizers[0].param_groups[0]["lr"] == pytest.approx(seq[e], rel=1e-9)
+    opt.lr_policy = "bogus"
+    assert isinstance(m.update_lr(opt), NotImplementedError)            # the reference returns, not raises (trainCas.py:61)
+
+
+def test_set_requires_grad():
+    d = srcgan_amd.NLayerDiscriminator(3, 16, 2)
+    T.set_requires_grad([d, None], False)
+    assert not any(p.requires_grad for p in d.parameters())
+    T.set_requires_grad(d, True)
+    assert all(p.requires_grad for p in d.parameters())
+
+
+def test_dtype_selection():
+    assert srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8).compute_dtype == "fp32"
+    assert srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8, dtype="bf16").compute_dtype == "bf16"
+    with pytest.raises(ValueError):
+        srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8, dtype="fp8")
