@@ -6,7 +6,7 @@ from srcgan_amd import ops
 
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
-B, H, W = 16, 256, 256
+B, H, W = int(os.environ.get("MB_B", "16")), 256, 256
 tdt = torch.bfloat16 if dt == "bf16" else torch.float32
 torch.manual_seed(0)
 dense = (torch.rand(B, H, W, 192, device="cuda") - 0.5).to(tdt)

@@ -59,3 +59,14 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // (bench.py: HIP events on the launch stream around the hot kernels; off by default -> zero cost)
 int sg_prof_start(const char* cls, double flops, double bytes, hipStream_t st);   // returns token or -1
 void sg_prof_stop(int token, hipStream_t st);
+
+// ---------------------------------------------------------------- batched weight packing (nets.hip -> elementwise.hip)
+struct SgPackJob {
+    const float* w; size_t wp_off;
+    int rows, kdim, tys, txs;
+    long sr, sk, sty, stx, off;
+    int k_off, k_total; float scale;
+    int cot, nchunk; long total, blk0;
+};
+void sg_pack_job_finish(SgPackJob& j, int dtype, long& blk_cursor);
+int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st);

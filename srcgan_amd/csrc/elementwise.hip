@@ -173,6 +173,48 @@ __global__ __launch_bounds__(256) void pack_weight_k(const float* __restrict__ w
     }
 }
 
+// Batched packing: one launch for every weight tensor of a network pass (a 23-block generator has 345 forward and
+// 1035 composite backward packs; one launch each instead of ~1400 x 4 us).  Block b serves job j with
+// jobs[j].blk0 <= b < jobs[j+1].blk0 (binary search); destinations are offsets from `wp_base` so the table can be
+// cached across calls while the workspace moves.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_k(const SgPackJob* __restrict__ jobs, int njobs, char* wp_base) {
+    constexpr int KCE = DT<T>::KCE;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].blk0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const SgPackJob j = jobs[lo];
+    const long e = ((long)blockIdx.x - j.blk0) * 256 + threadIdx.x;
+    if (e >= j.total) return;
+    T* wp = (T*)(wp_base + j.wp_off);
+    const int ntap = j.tys * j.txs;
+    long q = e;
+    const int kl = (int)(q % KCE); q /= KCE;
+    const int rl = (int)(q % j.cot); q /= j.cot;
+    const int tap = (int)(q % ntap); q /= ntap;
+    const int ch = (int)(q % j.nchunk);
+    const int rt = (int)(q / j.nchunk);
+    const int row = rt * j.cot + rl, kk = ch * KCE + kl - j.k_off;
+    const bool in = row < j.rows && kk >= 0 && kk < j.kdim;
+    if (in) wp[e] = from_f<T>(j.scale * j.w[j.off + row * j.sr + kk * j.sk + (tap / j.txs) * j.sty + (tap % j.txs) * j.stx]);
+    else if (j.k_off == 0 && j.kdim == j.k_total) wp[e] = from_f<T>(0.f);
+}
+
+void sg_pack_job_finish(SgPackJob& j, int dtype, long& blk_cursor) {
+    const int esz = dtype == SRCGAN_F32 ? 4 : 2, kce = 64 / esz;
+    j.cot = j.rows <= 32 ? 32 : 64;
+    j.nchunk = cdiv(j.k_total, kce);
+    j.total = (long)cdiv(j.rows, j.cot) * j.nchunk * j.tys * j.txs * j.cot * kce;
+    j.blk0 = blk_cursor;
+    blk_cursor += cdivl(j.total, 256);
+}
+
+int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st) {
+    if (njobs <= 0) return 0;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_multi_k<T>, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs, (char*)wp_base));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t srcgan_packed_weight_bytes(int rows, int kdim, int ntaps, int dtype) {
     const int esz = dtype == SRCGAN_F32 ? 4 : 2, kce = 64 / esz;
     const int cot = rows <= 32 ? 32 : 64;
@@ -235,6 +277,45 @@ __global__ __launch_bounds__(256) void col_reduce_k(const T* __restrict__ a, int
     }
 }
 
+// Vectorised variant (C % EPP == 0, (C/EPP) | 256): a thread owns EPP consecutive channels (one 16-byte load per
+// pixel) and every 256/(C/EPP)-th pixel, so a wave reads whole contiguous pixel records.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_vec_k(const T* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
+                                                        int zCs, int zcoff, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, long npix, int C,
+                                                        float* __restrict__ partial) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    __shared__ float red[2][256 * EPP];
+    const int G = C / EPP, PL = 256 / G;
+    const int cg = threadIdx.x % G, pl = threadIdx.x / G, c0 = cg * EPP;
+    const long per = cdivl(npix, gridDim.x);
+    const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    float s0[EPP], s1[EPP], mu[EPP], rs[EPP];
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) { s0[i] = 0.f; s1[i] = 0.f; mu[i] = MODE >= 1 ? mean[c0 + i] : 0.f; rs[i] = MODE == 2 ? rstd[c0 + i] : 0.f; }
+    for (long px = p0 + pl; px < p1; px += PL) {
+        const vecT av = *(const vecT*)(a + (size_t)px * aCs + acoff + c0);
+        if (MODE == 2) {
+            const vecT zv = *(const vecT*)(z + (size_t)px * zCs + zcoff + c0);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) { const float v = to_f(av[i]); s0[i] += v; s1[i] += v * (to_f(zv[i]) - mu[i]) * rs[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) { const float v = to_f(av[i]) - mu[i]; s0[i] += (MODE == 0) ? v : v * v; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) { red[0][threadIdx.x * EPP + i] = s0[i]; red[1][threadIdx.x * EPP + i] = s1[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int q = 0; q < PL; ++q) { t0 += red[0][(q * G + c / EPP) * EPP + c % EPP]; t1 += red[1][(q * G + c / EPP) * EPP + c % EPP]; }
+        partial[(size_t)blockIdx.x * C + c] = t0;
+        if (MODE == 2) partial[((size_t)gridDim.x + blockIdx.x) * C + c] = t1;
+    }
+}
+
 // one block per 64 channels; 4 block-lanes split the partials, fixed order
 __global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ partial, int nblk, int C, float scale,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
@@ -269,6 +350,16 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
     SG_REQUIRE(mode != 2 || (z && rstd && out1), "srcgan_col_reduce: mode 2 needs z, rstd, out1");
     const int nblk = srcgan_col_reduce_blocks(npix);
     hipStream_t st = (hipStream_t)stream;
+    const int epp = dtype == SRCGAN_F32 ? 4 : 8;
+    const bool vec = C % epp == 0 && 256 % (C / epp) == 0 && a_cs % epp == 0 && a_coff % epp == 0 && ((uintptr_t)a % 16) == 0 &&
+                     (mode != 2 || (z_cs % epp == 0 && z_coff % epp == 0 && ((uintptr_t)z % 16) == 0));
+    if (vec) {
+        DISPATCH_DTYPE(dtype, {
+            if (mode == 0) hipLaunchKernelGGL((col_reduce_vec_k<T, 0>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+            else if (mode == 1) hipLaunchKernelGGL((col_reduce_vec_k<T, 1>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+            else hipLaunchKernelGGL((col_reduce_vec_k<T, 2>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
+        });
+    } else
     DISPATCH_DTYPE(dtype, {
         if (mode == 0) hipLaunchKernelGGL((col_reduce_k<T, 0>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
         else if (mode == 1) hipLaunchKernelGGL((col_reduce_k<T, 1>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
@@ -312,21 +403,25 @@ extern "C" int srcgan_bn_eval_rstd(const float* running_var, float* rstd, int C,
     return 0;
 }
 
+// A thread owns EPP consecutive channels (their BN constants live in registers) and walks pixels: 16-byte
+// accesses, whole pixel records per wave, no per-element modulo or constant reloads.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ z, T* __restrict__ y, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, long n4, int C, int cs, float slope) {
-    // cs == C required (dense NHWC), C % 4 == 0
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-        const int c = (int)((e * 4) % cs);
-        float v[4];
-        load4<T>(z + e * 4, v);
+                                                  const float* __restrict__ beta, long npix, int C, float slope) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int G = C / EPP, PL = 256 / G;
+    const int c0 = (threadIdx.x % G) * EPP, pl = threadIdx.x / G;
+    float sc[EPP], sh[EPP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float u = (v[i] - mean[c + i]) * rstd[c + i] * gamma[c + i] + beta[c + i];
-            v[i] = u > 0.f ? u : u * slope;
-        }
-        store4<T>(y + e * 4, v);
+    for (int i = 0; i < EPP; ++i) { sc[i] = rstd[c0 + i] * gamma[c0 + i]; sh[i] = beta[c0 + i] - mean[c0 + i] * sc[i]; }
+    for (long px = (long)blockIdx.x * PL + pl; px < npix; px += (long)gridDim.x * PL) {
+        const vecT v = *(const vecT*)(z + (size_t)px * C + c0);
+        vecT o;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) { const float u = to_f(v[i]) * sc[i] + sh[i]; o[i] = from_f<T>(u > 0.f ? u : u * slope); }
+        *(vecT*)(y + (size_t)px * C + c0) = o;
     }
 }
 
@@ -334,29 +429,36 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* __restrict__ g, const T* __restrict__ z, T* __restrict__ dz,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ sum_g,
-                                                      const float* __restrict__ sum_gx, long n4, int cs, float invn) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-        const int c = (int)((e * 4) % cs);
-        float gv[4], zv[4];
-        load4<T>(g + e * 4, gv);
-        load4<T>(z + e * 4, zv);
+                                                      const float* __restrict__ sum_gx, long npix, int C, float invn) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int G = C / EPP, PL = 256 / G;
+    const int c0 = (threadIdx.x % G) * EPP, pl = threadIdx.x / G;
+    float ka[EPP], kb[EPP], kc[EPP], mu[EPP];          // dz = ka * (g - kb - (z - mu) * kc)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xh = (zv[i] - mean[c + i]) * rstd[c + i];
-            gv[i] = gamma[c + i] * rstd[c + i] * (gv[i] - sum_g[c + i] * invn - xh * sum_gx[c + i] * invn);
-        }
-        store4<T>(dz + e * 4, gv);
+    for (int i = 0; i < EPP; ++i) {
+        ka[i] = gamma[c0 + i] * rstd[c0 + i]; kb[i] = sum_g[c0 + i] * invn;
+        kc[i] = rstd[c0 + i] * sum_gx[c0 + i] * invn; mu[i] = mean[c0 + i];
+    }
+    for (long px = (long)blockIdx.x * PL + pl; px < npix; px += (long)gridDim.x * PL) {
+        const vecT gv = *(const vecT*)(g + (size_t)px * C + c0);
+        const vecT zv = *(const vecT*)(z + (size_t)px * C + c0);
+        vecT o;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(ka[i] * (to_f(gv[i]) - kb[i] - (to_f(zv[i]) - mu[i]) * kc[i]));
+        *(vecT*)(dz + (size_t)px * C + c0) = o;
     }
 }
-
 
 extern "C" int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, long npix, int C, int cs, float slope, int dtype, void* stream) {
     SG_REQUIRE(z && y && mean && rstd && gamma && beta && npix > 0, "srcgan_bn_apply_lrelu: bad arguments");
-    SG_REQUIRE(cs == C && C % 4 == 0, "srcgan_bn_apply_lrelu: needs a dense NHWC tensor with C %% 4 == 0 (C=%d cs=%d)", C, cs);
-    const long n4 = npix * C / 4;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
-                                             (const T*)z, (T*)y, mean, rstd, gamma, beta, n4, C, cs, slope));
+    const int epp = dtype == SRCGAN_F32 ? 4 : 8;
+    SG_REQUIRE(cs == C && C % epp == 0 && 256 % (C / epp) == 0,
+               "srcgan_bn_apply_lrelu: needs a dense NHWC tensor with C a multiple of %d and C/%d dividing 256 (C=%d cs=%d)", epp, epp, C, cs);
+    const int pl = 256 / (C / epp);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_blocks(npix, pl * 4)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)z, (T*)y, mean, rstd, gamma, beta, npix, C, slope));
     SG_LAUNCH_CHECK();
     return 0;
 }
@@ -365,10 +467,12 @@ extern "C" int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const
                                    const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
                                    int dtype, void* stream) {
     SG_REQUIRE(g && z && dz && mean && rstd && gamma && sum_g && sum_gx && npix > 0, "srcgan_bn_bwd_apply: bad arguments");
-    SG_REQUIRE(cs == C && C % 4 == 0, "srcgan_bn_bwd_apply: needs a dense NHWC tensor with C %% 4 == 0");
-    const long n4 = npix * C / 4;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
-                                             (const T*)g, (const T*)z, (T*)dz, mean, rstd, gamma, sum_g, sum_gx, n4, cs,
+    const int epp = dtype == SRCGAN_F32 ? 4 : 8;
+    SG_REQUIRE(cs == C && C % epp == 0 && 256 % (C / epp) == 0,
+               "srcgan_bn_bwd_apply: needs a dense NHWC tensor with C a multiple of %d and C/%d dividing 256", epp, epp);
+    const int pl = 256 / (C / epp);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_blocks(npix, pl * 4)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)g, (const T*)z, (T*)dz, mean, rstd, gamma, sum_g, sum_gx, npix, C,
                                              1.f / (float)npix));
     SG_LAUNCH_CHECK();
     return 0;

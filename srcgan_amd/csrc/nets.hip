@@ -14,6 +14,8 @@
 // buffer per block that the dgrads of conv5..conv1 accumulate into in place.
 #include "common.h"
 #include <vector>
+#include <map>
+#include <string>
 
 namespace {
 
@@ -76,6 +78,41 @@ static size_t wgrad_slab(int B, int OH, int OW, int Cout, int Cin, int kh, int k
 static int bias_grad(int dtype, TRef dy, long npix, int C, float scale, float* out, float* scratch, void* st) {
     return srcgan_col_reduce(0, dy.p, dy.cs, dy.coff, nullptr, 0, 0, nullptr, nullptr, npix, C, scale, out, nullptr, scratch, dtype, st);
 }
+
+// ---- batched weight packing with a cached device-side job table
+struct PackCache { std::vector<SgPackJob> host; SgPackJob* dev = nullptr; size_t cap = 0; };
+static std::map<std::string, PackCache> g_pack_cache;
+
+struct PackList {
+    std::vector<SgPackJob> jobs; long nblk = 0; int dtype; char* base;
+    PackList(int dt, void* wp_base) : dtype(dt), base((char*)wp_base) {}
+    void add(const float* w, void* wp, int rows, int kdim, int tys, int txs, long sr, long sk, long sty, long stx, long off,
+             int k_off = 0, int k_total = -1, float scale = 1.f) {
+        SgPackJob j;
+        memset(&j, 0, sizeof(j));
+        j.w = w; j.wp_off = (size_t)((char*)wp - base); j.rows = rows; j.kdim = kdim; j.tys = tys; j.txs = txs;
+        j.sr = sr; j.sk = sk; j.sty = sty; j.stx = stx; j.off = off; j.k_off = k_off; j.k_total = k_total < 0 ? kdim : k_total; j.scale = scale;
+        sg_pack_job_finish(j, dtype, nblk);
+        jobs.push_back(j);
+    }
+    int run(const char* tag, const void* key_ptr, void* st) {
+        if (jobs.empty()) return 0;
+        char key[96];
+        snprintf(key, sizeof(key), "%s:%p:%d:%zu", tag, key_ptr, dtype, jobs.size());
+        PackCache& c = g_pack_cache[key];
+        const size_t bytes = jobs.size() * sizeof(SgPackJob);
+        if (c.host.size() != jobs.size() || memcmp(c.host.data(), jobs.data(), bytes) != 0) {
+            if (c.cap < bytes) {
+                if (c.dev) SG_HIP(hipFree(c.dev));
+                SG_HIP(hipMalloc((void**)&c.dev, bytes));
+                c.cap = bytes;
+            }
+            SG_HIP(hipMemcpy(c.dev, jobs.data(), bytes, hipMemcpyHostToDevice));     // cold path: first call / parameters moved
+            c.host = jobs;
+        }
+        return sg_pack_multi_launch(c.dev, (int)jobs.size(), nblk, base, dtype, (hipStream_t)st);
+    }
+};
 
 // ======================================================================================== RDDBNet
 struct RddbPlan {
@@ -210,20 +247,23 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
     auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
     auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.C); };
 
-    // ---- pack weights for this call (f32 canonical -> dtype, MFMA-friendly)
-    SG_TRY(srcgan_pack_weight(params[P.p_first_w], wp + P.w_first_f, nf, c->in_ch, 3, 3, (long)c->in_ch * 9, 9, 3, 1, 0, dt, st));
+    // ---- pack weights for this call (f32 canonical -> dtype, MFMA-friendly): ONE batched launch
+    PackList packs(dt, wp);
+    packs.add(params[P.p_first_w], wp + P.w_first_f, nf, c->in_ch, 3, 3, (long)c->in_ch * 9, 9, 3, 1, 0);
     for (int s = 0; s < P.ndn; ++s)
-        SG_TRY(srcgan_pack_weight(params[P.p_dn0 + 2 * s], wp + P.w_dn_f[s], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+        packs.add(params[P.p_dn0 + 2 * s], wp + P.w_dn_f[s], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     for (int i = 0; i < c->nb * 3; ++i)
         for (int k = 0; k < 5; ++k) {
             const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
-            SG_TRY(srcgan_pack_weight(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0, dt, st));
+            packs.add(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0);
         }
-    SG_TRY(srcgan_pack_weight(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+    packs.add(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     for (int s = 0; s < P.nst; ++s)
         for (int q = 0; q < 4; ++q)   // ConvTranspose2d weight [ci][co][2][2]; parity (a,b) = q: rows = co, k = ci
-            SG_TRY(srcgan_pack_weight(params[P.p_up0 + s], wp + P.w_up_f[s][q], nf, nf, 1, 1, 4, (long)nf * 4, 0, 0, q, dt, st));
-    SG_TRY(srcgan_pack_weight(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0, dt, st));
+            packs.add(params[P.p_up0 + s], wp + P.w_up_f[s][q], nf, nf, 1, 1, 4, (long)nf * 4, 0, 0, q);
+    packs.add(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
+
+    SG_TRY(packs.run("rddb_fwd", params[0], st));
 
     // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -296,13 +336,14 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     auto G = [&](int idx) { return grads[idx]; };
     const long npix_t = (long)B * H * W;
 
-    // ---- packed dgrad weights (flipped / transposed views of the canonical tensors)
+    // ---- packed dgrad weights (flipped / transposed views of the canonical tensors): ONE batched launch
     {
+        PackList packs(dt, wp);
         const WLayout L = lay_dgrad_s1(nf, 3, 3);
-        SG_TRY(srcgan_pack_weight(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off, dt, st));
+        packs.add(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         for (int s = 0; s < P.nst; ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
-            SG_TRY(srcgan_pack_weight(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0, dt, st));
-        SG_TRY(srcgan_pack_weight(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off, dt, st));
+            packs.add(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0);
+        packs.add(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         SG_HIP(hipMemsetAsync(wp + P.w_rdb_d0, 0, P.w_rdb_dsz, (hipStream_t)st));
         for (int r = 0; r < c->nb * 3; ++r) {
             const float a5 = (r % 3 == 2) ? 0.04f : 0.2f;       // d(x5)/d(block out), RDB3 carries the RRDB 0.2 too
@@ -311,8 +352,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                 for (int m = 5; m > j; --m) {                   // block of K coming from forward conv m
                     const int cin_m = nf + (m - 1) * gc, cout_m = m == 5 ? nf : gc;
                     const int k_off = m == 5 ? 0 : nf + (4 - m) * gc;
-                    SG_TRY(srcgan_pack_weight_part(params[P.p_rdb0 + (r * 5 + m - 1) * 2], wp + P.w_rdb_d[r * 5 + j], rows, cout_m, 3, 3,
-                                                   9, (long)cin_m * 9, -3, -1, (long)ss * 9 + 8, k_off, ktot, m == 5 ? a5 : 1.f, dt, st));
+                    packs.add(params[P.p_rdb0 + (r * 5 + m - 1) * 2], wp + P.w_rdb_d[r * 5 + j], rows, cout_m, 3, 3,
+                                                   9, (long)cin_m * 9, -3, -1, (long)ss * 9 + 8, k_off, ktot, m == 5 ? a5 : 1.f);
                 }
             }
         }
@@ -322,12 +363,13 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                 const int a = q >> 1, bb = q & 1;
                 const int ty = a ? 2 : 1, tx = bb ? 2 : 1;
                 const long off = (a ? 2 : 1) * 3 + (bb ? 2 : 1);
-                SG_TRY(srcgan_pack_weight(params[P.p_dn0 + 2 * s], wp + P.w_dn_d[s][q], nf, nf, ty, tx, 9, (long)nf * 9, -6, -2, off, dt, st));
+                packs.add(params[P.p_dn0 + 2 * s], wp + P.w_dn_d[s][q], nf, nf, ty, tx, 9, (long)nf * 9, -6, -2, off);
             }
         if (dx_nchw) {
             const WLayout L0 = lay_dgrad_s1(c->in_ch, 3, 3);
-            SG_TRY(srcgan_pack_weight(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off, dt, st));
+            packs.add(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off);
         }
+        SG_TRY(packs.run(dx_nchw ? "rddb_bwd_dx" : "rddb_bwd", params[0], st));
     }
 
     // ---- dy: NCHW f32 -> NHWC
@@ -545,8 +587,12 @@ extern "C" int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* 
     SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_nlayerd_forward: workspace must be 256-byte aligned");
     const int dt = c->dtype, B = c->B;
     char* w8 = (char*)ws; char* wp = w8 + P.wpk;
-    for (int l = 0; l < P.L; ++l)
-        SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wf[l], P.ch[l + 1], P.ch[l], 4, 4, (long)P.ch[l] * 16, 16, 4, 1, 0, dt, st));
+    {
+        PackList packs(dt, wp);
+        for (int l = 0; l < P.L; ++l)
+            packs.add(params[P.pw[l]], wp + P.wf[l], P.ch[l + 1], P.ch[l], 4, 4, (long)P.ch[l] * 16, 16, 4, 1, 0);
+        SG_TRY(packs.run("d_fwd", params[0], st));
+    }
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
     TRef cur = tref(w8 + P.xin, P.in_cs);
     for (int l = 0; l < P.L; ++l) {
@@ -599,18 +645,20 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
     char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
     float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr); float* sums = (float*)(s8 + Q.sums);
     // ---- packed dgrad weights
+    PackList packs(dt, wp);
     for (int l = 0; l < P.L; ++l) {
         if (l == 0 && !dx_nchw) continue;
         const int cin = P.ch[l], cout = P.ch[l + 1];
         if (P.st[l] == 1)
-            SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wd[l][0], cin, cout, 4, 4, 16, (long)cin * 16, -4, -1, 15, dt, st));
+            packs.add(params[P.pw[l]], wp + P.wd[l][0], cin, cout, 4, 4, 16, (long)cin * 16, -4, -1, 15);
         else
             for (int q = 0; q < 4; ++q) {   // stride-2 dgrad by output parity (a,b): 2x2 sub-kernel, ky = (a?2:3) - 2*ty
                 const int a = q >> 1, bb = q & 1;
                 const long off = (a ? 2 : 3) * 4 + (bb ? 2 : 3);
-                SG_TRY(srcgan_pack_weight(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off, dt, st));
+                packs.add(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off);
             }
     }
+    SG_TRY(packs.run(dx_nchw ? "d_bwd_dx" : "d_bwd", params[0], st));
     // ---- dy -> NHWC (1 channel, padded with zeros to 8)
     const int Lh = P.hh[P.L], Lw = P.ww[P.L];
     TRef dcur = tref(s8 + Q.dO, P.out_cs);
