@@ -17,7 +17,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
-__device__ __attribute__((aligned(64))) unsigned int sg_zero_page[16];
+static __device__ __attribute__((aligned(64))) unsigned int sg_zero_page[16];
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

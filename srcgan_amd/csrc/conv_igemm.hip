@@ -238,6 +238,8 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
 }
 
 int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st);      // conv3x3_dma.hip
+int sg_conv3x3_pipe(const ConvP& p, int dtype, hipStream_t st);     // conv3x3_pipe.hip
+static const bool g_use_pipe = getenv("SRCGAN_PIPE") != nullptr;
 static const bool g_force_generic = getenv("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
 
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
@@ -280,7 +282,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && !g_force_generic) return sg_conv3x3_dma(p, d->dtype, st);
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && !g_force_generic) return g_use_pipe ? sg_conv3x3_pipe(p, d->dtype, st) : sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);

@@ -144,6 +144,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, const f32x16 (
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
         *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
     }
+    // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
+    // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
+    // serialised the LDS-DMA ring).
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) asm volatile("" :: "v"(bias[i]));
 }
 
 // One output row (32 pixels) of the LDS-transposed epilogue: transpose space = 32 * (COT*4+16) bytes per wave.
@@ -202,9 +207,80 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
         *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
     }
+    // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
+    // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
+    // serialised the LDS-DMA ring).
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) asm volatile("" :: "v"(bias[i]));
 }
 template <typename T, int MT, int PT>
 __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
                                                       int oy, int ox0, int lane) {
     conv_epilogue_lds_row_impl<T, MT, PT>(p, acc, q, lds_wave, b, ct, oy, ox0, lane);
+}
+
+// Half-row (16 pixels) variant for kernels whose free LDS slot is small: transpose space = 16 * (COT*4+16) bytes per wave.
+template <typename T, int MT, int PT>
+__device__ __forceinline__ void conv_epilogue_lds_half(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, int half, char* lds_wave,
+                                                       int b, int ct, int oy, int ox0, int lane) {
+    constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP;
+    constexpr int RS = COT * 4 + 16;
+    const int r = lane & 31, h = lane >> 5;
+    if ((r >> 4) == half) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+                *(f32x4*)(lds_wave + (r & 15) * RS + (m * 32 + 8 * g + 4 * h) * 4) = v;
+            }
+    }
+    const int cpart = lane % LPP, c0 = cpart * EPP, co0 = ct * COT + c0;
+    const bool cok = co0 < p.Cout;
+    float bias[EPP];
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) bias[i] = 0.f;
+    if (p.bias && cok) {
+#pragma unroll
+        for (int i = 0; i < EPP; i += 4) { const f32x4 bv = *(const f32x4*)(p.bias + co0 + i); bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3]; }
+    }
+    const bool use_r1 = p.r1 && co0 < p.r1cend, use_r2 = p.r2 && co0 < p.r2cend, use_mz = p.mz && co0 >= p.mzc0;
+#pragma unroll
+    for (int pass = 0; pass < (16 + PPP - 1) / PPP; ++pass) {
+        const int pix = pass * PPP + lane / LPP;
+        if (PPP > 16 && pix >= 16) continue;
+        const int ox = ox0 + half * 16 + pix;
+        float v[EPP];
+#pragma unroll
+        for (int i = 0; i < EPP; i += 4) {
+            const f32x4 t = *(const f32x4*)(lds_wave + pix * RS + (c0 + i) * 4);
+            v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+        }
+        if (!cok || oy >= p.OH || ox >= p.OW) continue;
+        const size_t opix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + (size_t)ox * p.os + p.ob;
+        typedef __attribute__((ext_vector_type(EPP))) T vecT;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
+        if (use_r1) { const vecT t = *(const vecT*)((const T*)p.r1 + opix * p.r1Cs + p.r1coff + co0);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
+        if (use_r2) { const vecT t = *(const vecT*)((const T*)p.r2 + opix * p.r2Cs + p.r2coff + co0);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
+        if (p.act) {
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
+        if (use_mz) { const vecT t = *(const vecT*)((const T*)p.mz + opix * p.mzCs + p.mzcoff + co0);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) v[i] *= (to_f(t[i]) > 0.f ? 1.f : p.mslope); }
+        vecT o;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
+        *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
+    }
+    // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
+    // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
+    // serialised the LDS-DMA ring).
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) asm volatile("" :: "v"(bias[i]));
 }
