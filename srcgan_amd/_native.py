@@ -65,6 +65,18 @@ class WgradDesc(C.Structure):
                 ("alpha", C.c_float), ("accumulate", C.c_int)]
 
 
+class WgradSeg(C.Structure):
+    _fields_ = [("g0", C.c_int), ("g1", C.c_int), ("grad", C.c_void_p), ("bias", C.c_void_p), ("Cin", C.c_int), ("alpha", C.c_float)]
+
+
+class WgradDenseDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("dtype", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("G", C.c_int), ("dy_cs", C.c_int), ("dy_coff", C.c_int),
+                ("C", C.c_int), ("x_cs", C.c_int), ("x_coff", C.c_int),
+                ("nseg", C.c_int), ("seg", WgradSeg * 8), ("accumulate", C.c_int)]
+
+
 class RddbCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("up", C.c_int), ("nf", C.c_int), ("nb", C.c_int), ("gc", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("down", C.c_int)]
@@ -91,6 +103,8 @@ SIGNATURES = {
     "srcgan_conv_wgrad_slab_bytes": (_S, [_I, _I, _I, _I, _I]),
     "srcgan_conv_wgrad_nsplit": (_I, [_I, _I, _I, _I, _I, _I]),
     "srcgan_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P]),
+    "srcgan_wgrad_dense_slab_bytes": (_S, [_I, _I, _I, _I, _I, _I]),
+    "srcgan_wgrad_dense": (_I, [C.POINTER(WgradDenseDesc), _P]),
     "srcgan_col_reduce_blocks": (_I, [_L]),
     "srcgan_col_reduce": (_I, [_I, _P, _I, _I, _P, _I, _I, _P, _P, _L, _I, _F, _P, _P, _P, _I, _P]),
     "srcgan_bn_finalize": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _P]),

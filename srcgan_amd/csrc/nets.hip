@@ -223,6 +223,7 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     for (int s = 0; s < P.nst; ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
     for (int s = 0; s < P.ndn; ++s) mx(wgrad_slab(c->B, c->H >> (s + 1), c->W >> (s + 1), c->nf, c->nf, 3, 3, 2));
     mx(wgrad_slab(c->B, P.HO, P.WO, c->out_ch, c->nf, 3, 3, 1));
+    mx(srcgan_wgrad_dense_slab_bytes(P.C, P.C, c->dtype, c->B, P.Ht, P.Wt));
     Q.slab = b.take(slab);
     const long maxpix = (long)B * (P.HO > c->H ? P.HO : c->H) * (P.WO > c->W ? P.WO : c->W);
     Q.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks(maxpix) * P.C * sizeof(float));
@@ -416,15 +417,6 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             const float bres = (j3 == 2) ? 0.2f : 1.f;     // block-input residual: d(in) += bres * d(out)
             const int pbase = P.p_rdb0 + r * 10;
             for (int m = 5; m >= 1; --m) {
-                // dy_m is final here: weight/bias gradient of forward conv m
-                const int cin_m = nf + (m - 1) * gc, cout_m = m == 5 ? nf : gc;
-                TRef dym = sl(Gd, m == 5 ? 0 : nf + (4 - m) * gc);
-                const float am = m == 5 ? a5 : 1.f;
-                if (G(pbase + 2 * (m - 1)))
-                    SG_TRY(wgrad_call(dt, dym, H, W, cout_m, A, B, H, W, cin_m, 3, 3, 1, 1, 1, lay_fwd(cin_m, 3, 3), am, slab,
-                                      G(pbase + 2 * (m - 1)), st, G(pbase + 2 * (m - 1) + 1)));
-                else if (G(pbase + 2 * (m - 1) + 1))
-                    SG_TRY(bias_grad(dt, dym, npix_t, cout_m, am, G(pbase + 2 * (m - 1) + 1), colscr, st));
                 // gradient of input slice j = m-1 from [dy5 .. dy_m]
                 const int j = m - 1, ktot = nf + (4 - j) * gc;
                 Conv cv(dt, 3, 3, 1);
@@ -437,6 +429,23 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                     if (j3 == 0) cv.res2(nxt, nf, 1.f);     // RRDB skip; nxt == Pg(0) still holds d(out_rrdb): in-place, same element
                 }
                 SG_TRY(cv.run(st));
+            }
+            // weight + bias gradients of the block's five convs in ONE pass over (Gd, A) -- wgrad_dense.hip
+            {
+                srcgan_wgrad_dense_desc wd;
+                memset(&wd, 0, sizeof(wd));
+                wd.dy = Gd.p; wd.dy_cs = Gd.cs; wd.dy_coff = Gd.coff; wd.G = P.C;
+                wd.x = A.p; wd.x_cs = A.cs; wd.x_coff = A.coff; wd.C = P.C;
+                wd.slab = slab; wd.dtype = dt; wd.B = B; wd.H = H; wd.W = W;
+                bool any = false;
+                for (int m = 5; m >= 1; --m) {
+                    srcgan_wgrad_seg& sg = wd.seg[wd.nseg++];
+                    sg.g0 = m == 5 ? 0 : nf + (4 - m) * gc; sg.g1 = sg.g0 + (m == 5 ? nf : gc);
+                    sg.grad = G(pbase + 2 * (m - 1)); sg.bias = G(pbase + 2 * (m - 1) + 1);
+                    sg.Cin = nf + (m - 1) * gc; sg.alpha = m == 5 ? a5 : 1.f;
+                    any = any || sg.grad || sg.bias;
+                }
+                if (any) SG_TRY(srcgan_wgrad_dense(&wd, st));
             }
         }
     }

@@ -1,0 +1,306 @@
+// Dense-block weight gradient: ONE pass over a block's activation buffer A (nf+4gc channels) and its dense
+// gradient buffer Gd = [dy5|dy4|dy3|dy2|dy1] produces the weight and bias gradients of all five 3x3 convolutions of a
+// ResidualDenseBlock_5 (reference src/model/rddb.py:52-68; replaces five aten::convolution_backward wgrad calls).
+//
+// Why: the per-conv wgrad kernel (conv_wgrad.hip) stages 32x32 or 64x32 (Cout x Cin) tiles = 124-190 FLOP per staged
+// byte and measured HBM-bound (1.1 GB fetched per launch, 6.4 TB/s, 383-533 TFLOP/s).  Here a workgroup owns a
+// (up to 128 gradient channels) x (64 input channels) x 9 taps block: 346 FLOP per staged byte; 64 input channels =
+// full 128-byte lines of the NHWC buffers.  Each wave owns one 32x32 (g-tile, ci-tile) pair and keeps all nine taps'
+// accumulators (+ the bias pseudo-tap, B operand = ones) in registers across its pixel range; split-K over pixel
+// ranges into an f32 slab; a segment-aware reduce scatters rows to the five canonical [Cout,Cin,3,3] gradients
+// (rows of a tile may belong to different convolutions with different Cin; surplus columns are dropped).
+#include "common.h"
+#include <type_traits>
+
+struct WdSeg { int g0, g1; float* grad; float* bias; int Cin; float alpha; };
+struct WdP {
+    const void* dy; const void* x; float* slab;
+    int B, H, W, G, C, dyCs, dycoff, xCs, xcoff;
+    int g_base;                 // first gradient channel of this launch's row group
+    int nsplit, tiles_x, tiles_y, ntiles, ncit, want_bias;
+};
+struct WdRedP {
+    const float* slab; int nsplit, ncit, COT, g_base, nseg; WdSeg seg[8]; int accumulate;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_;
+__device__ __forceinline__ bf16x8 tr_frag2(const char* p0, const char* p1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_*)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_*)(p1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+static __device__ __attribute__((aligned(64))) unsigned int wd_zero_page[16];
+typedef const __attribute__((address_space(1))) void* wd_gptr_t;
+typedef __attribute__((address_space(3))) void* wd_lptr_t;
+
+// Operands arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a double-buffered LDS image
+// of 32-channel planes [pixel][32 ch] (no staging registers: the 10 accumulators already take 160 VGPRs).
+template <typename T, int MT, int NT, int TH>
+__global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
+    using D = DT<T>;
+    constexpr int NW = MT * NT, TW = 32, NTAP = 9;
+    constexpr int IHT = TH + 2, IWT = TW + 2;
+    constexpr int PB = 32 * (int)sizeof(T), PPP = PB / 16, PXP = 64 / PPP;      // pixels per 1-KiB piece
+    constexpr int DPX = TH * TW, XPX = IHT * IWT;                               // pixels per plane
+    constexpr int DPP = (DPX + PXP - 1) / PXP, XPP = (XPX + PXP - 1) / PXP;     // pieces per plane
+    constexpr int DBYTES = DPP * 1024, XBYTES = XPP * 1024;
+    constexpr int NPIECE = MT * DPP + NT * XPP, SBYTES = MT * DBYTES + NT * XBYTES;
+    constexpr int IPW = (NPIECE + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];               // [2 stages][MT dy planes | NT x planes]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave / NT, wn = wave % NT;        // this wave's (g-tile, ci-tile)
+    const int cit = blockIdx.x, split = blockIdx.y;
+    const bool do_bias = wn == 0 && cit == 0 && p.want_bias;
+    const char* zp = (const char*)wd_zero_page;
+
+    f32x16 acc[NTAP + 1];
+#pragma unroll
+    for (int a = 0; a <= NTAP; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+    const int t_begin = (int)((long)p.ntiles * split / p.nsplit);
+    const int t_end = (int)((long)p.ntiles * (split + 1) / p.nsplit);
+
+    auto issue = [&](int t, int stage) {
+        int q = t;
+        const int tx = q % p.tiles_x; q /= p.tiles_x;
+        const int ty = q % p.tiles_y;
+        const int b = q / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const char* dyb = (const char*)p.dy + ((size_t)b * p.H * p.W * p.dyCs + p.dycoff) * sizeof(T);
+        const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+        char* ls = smem + stage * SBYTES;
+#pragma unroll
+        for (int it = 0; it < IPW; ++it) {
+            const int pi = it * NW + wave;                    // wave-uniform piece id
+            if (IPW * NW != NPIECE && pi >= NPIECE) continue;
+            const char* src = zp;
+            const int part = lane % PPP, lpx = lane / PPP;
+            if (pi < MT * DPP) {
+                const int m = pi / DPP, pix = (pi - m * DPP) * PXP + lpx;
+                const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+                const int ch = p.g_base + m * 32 + part * D::EPP;
+                if (pix < DPX && oy < p.H && ox < p.W && ch < p.G) src = dyb + ((size_t)(oy * p.W + ox) * p.dyCs + ch) * sizeof(T);
+            } else {
+                const int pj = pi - MT * DPP, n = pj / XPP, pix = (pj - n * XPP) * PXP + lpx;
+                const int iy = pix / IWT, ix = pix - iy * IWT;
+                const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+                const int ch = (cit * NT + n) * 32 + part * D::EPP;
+                if (pix < XPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.C)
+                    src = xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T);
+            }
+            __builtin_amdgcn_global_load_lds((wd_gptr_t)src, (wd_lptr_t)(ls + pi * 1024), 16, 0, 0);
+        }
+    };
+
+    if (t_begin < t_end) issue(t_begin, 0);
+    int stage = 0;
+    for (int t = t_begin; t < t_end; ++t, stage ^= 1) {
+        __syncthreads();            // own DMAs of tile t landed (vmcnt(0)); everyone is done with the other stage
+        if (t + 1 < t_end) issue(t + 1, stage ^ 1);
+        const char* my_d = smem + stage * SBYTES + wm * DBYTES;
+        const char* my_x = smem + stage * SBYTES + MT * DBYTES + wn * XBYTES;
+        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll 2
+            for (int kk = 0; kk < TH * TW / 2; ++kk) {
+                const int pix = 2 * kk + h;
+                const int py = pix / TW, px = pix % TW;
+                const float a = *(const float*)(my_d + pix * PB + r * 4);
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const float bv = *(const float*)(my_x + ((py + ky) * IWT + px + kx) * PB + r * 4);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tap], 0, 0, 0);
+                }
+                if (do_bias) acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[NTAP], 0, 0, 0);
+            }
+        } else {
+            const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
+            const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
+            bf16x8 ones;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#pragma unroll 2
+            for (int kk = 0; kk < TH * 2; ++kk) {
+                const int py = kk >> 1, xh = (kk & 1) * 16;
+                const int px0 = xh + 8 * h + qq;
+                const char* ab = my_d + (py * TW + px0) * PB + choff;
+                const bf16x8 a = tr_frag2(ab, ab + 4 * PB);
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const char* bb = my_x + ((py + ky) * IWT + px0 + kx) * PB + choff;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_frag2(bb, bb + 4 * PB), acc[tap], 0, 0, 0);
+                }
+                if (do_bias) acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[NTAP], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- slab [split][cit][tap (10)][row (32*MT)][col (32*NT)];  acc[.][4g+i] = D[row = 8g+4h+i][col = r]
+    constexpr int COT = 32 * MT, CIT = 32 * NT;
+    float* sp = p.slab + ((size_t)split * p.ncit + cit) * (NTAP + 1) * COT * CIT;
+#pragma unroll
+    for (int tap = 0; tap <= NTAP; ++tap) {
+        if (tap == NTAP && !do_bias) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            sp[((size_t)tap * COT + row) * CIT + wn * 32 + r] = acc[tap][i];
+        }
+    }
+}
+
+// 64 slab elements x 4 split lanes per block; fixed order -> deterministic.  Scatter by segment.
+template <int CIT>
+__global__ __launch_bounds__(256) void wgrad_dense_reduce_k(const WdRedP p) {
+    __shared__ float red[4][64];
+    const long per_split = (long)p.ncit * 10 * p.COT * CIT;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (e < per_split)
+        for (int sp = sl; sp < p.nsplit; sp += 4) s += p.slab[(size_t)sp * per_split + e];
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl != 0 || e >= per_split) return;
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    long q = e;
+    const int col = (int)(q % CIT); q /= CIT;
+    const int row = (int)(q % p.COT); q /= p.COT;
+    const int tap = (int)(q % 10);
+    const int cit = (int)(q / 10);
+    const int g = p.g_base + row, ci = cit * CIT + col;
+    for (int k = 0; k < p.nseg; ++k) {
+        const WdSeg sg = p.seg[k];
+        if (g < sg.g0 || g >= sg.g1) continue;
+        const int co = g - sg.g0;
+        const float v = s * sg.alpha;
+        if (tap == 9) {
+            if (sg.bias && cit == 0 && col == 0) sg.bias[co] = p.accumulate ? sg.bias[co] + v : v;
+        } else if (sg.grad && ci < sg.Cin) {
+            float* gp = sg.grad + ((size_t)co * sg.Cin + ci) * 9 + tap;
+            *gp = p.accumulate ? *gp + v : v;
+        }
+        return;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T, int MT, int NT, int TH>
+static int launch_wd(WdP p, hipStream_t st) {
+    constexpr int PB = 32 * (int)sizeof(T), PXP = 64 / (PB / 16);
+    constexpr size_t SMEM = 2 * 1024 * ((size_t)MT * ((TH * 32 + PXP - 1) / PXP) + (size_t)NT * (((TH + 2) * 34 + PXP - 1) / PXP));
+    static_assert(SMEM <= 160 * 1024, "wgrad_dense tile exceeds LDS");
+    auto kern = wgrad_dense_k<T, MT, NT, TH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set = true;
+    }
+    p.tiles_x = cdiv(p.W, 32);
+    p.tiles_y = cdiv(p.H, TH);
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
+    char cls[96];
+    snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NT);
+    const double px = (double)p.B * p.H * p.W;
+    const int rows = (p.G - p.g_base) < 32 * MT ? (p.G - p.g_base) : 32 * MT;
+    const int tok = sg_prof_start(cls, 2.0 * px * 9 * rows * (double)(p.ncit * 32 * NT < p.C ? p.ncit * 32 * NT : p.C),
+                                  px * (rows + p.C) * sizeof(T), st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.ncit, (unsigned)p.nsplit), dim3(MT * NT * 64), SMEM, st, p);
+    sg_prof_stop(tok, st);
+    SG_LAUNCH_CHECK();
+    return p.nsplit;
+}
+
+template <typename T>
+static int dispatch_wd(const WdP& p, int mt, hipStream_t st, int& nsplit_used) {
+    constexpr bool F = std::is_same<T, float>::value;
+    int rc = -1;
+    switch (mt) {
+        case 1: rc = launch_wd<T, 1, 2, F ? 2 : 4>(p, st); break;
+        case 2: rc = launch_wd<T, 2, 2, F ? 2 : 4>(p, st); break;
+        case 3: rc = launch_wd<T, 3, 2, F ? 2 : 4>(p, st); break;
+        case 4: rc = launch_wd<T, 4, 2, F ? 2 : 4>(p, st); break;
+    }
+    if (rc < 0) SG_FAIL("srcgan_wgrad_dense: bad row-tile count %d", mt);
+    nsplit_used = rc;
+    return 0;
+}
+
+// pixel splits per row group: fill the chip once (workgroups resident per CU follow from the LDS tile)
+static int wd_nsplit(int mt, int ncit, int dtype, int B, int H, int W) {
+    const int th = dtype == SRCGAN_F32 ? 2 : 4;
+    const int pb = dtype == SRCGAN_F32 ? 128 : 64;
+    const long lds = 2 * ((long)mt * th * 32 * pb + 2L * (th + 2) * 34 * pb);
+    int per_cu = (int)((160 * 1024) / lds); if (per_cu < 1) per_cu = 1;
+    if (per_cu * mt * 2 > 16) per_cu = 16 / (mt * 2) > 0 ? 16 / (mt * 2) : 1;      // <= 16 waves per CU
+    const long ntiles = (long)B * cdiv(H, th) * cdiv(W, 32);
+    long ns = (256L * per_cu) / ncit;
+    if (ns > ntiles) ns = ntiles;
+    return (int)(ns < 1 ? 1 : ns);
+}
+
+extern "C" size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, int H, int W) {
+    size_t mx = 0;
+    for (int g_base = 0; g_base < G; g_base += 128) {
+        const int rows = G - g_base < 128 ? G - g_base : 128, mt = cdiv(rows, 32), ncit = cdiv(C, 64);
+        const size_t b = (size_t)wd_nsplit(mt, ncit, dtype, B, H, W) * ncit * 10 * (32 * mt) * 64 * sizeof(float);
+        if (b > mx) mx = b;
+    }
+    return mx;
+}
+
+extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream) {
+    SG_REQUIRE(d && d->dy && d->x && d->slab, "srcgan_wgrad_dense: null pointer");
+    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_wgrad_dense: bad dtype %d", d->dtype);
+    const int esz = d->dtype == SRCGAN_F32 ? 4 : 2, epp = 16 / esz;
+    SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->G > 0 && d->C > 0 && d->nseg > 0 && d->nseg <= 8,
+               "srcgan_wgrad_dense: bad dimensions");
+    SG_REQUIRE(d->G % epp == 0 && d->C % epp == 0 && d->dy_cs % epp == 0 && d->dy_coff % epp == 0 && d->x_cs % epp == 0 && d->x_coff % epp == 0,
+               "srcgan_wgrad_dense: channel counts/strides/offsets must be multiples of %d", epp);
+    SG_REQUIRE(d->dy_coff + d->G <= d->dy_cs && d->x_coff + d->C <= d->x_cs, "srcgan_wgrad_dense: channel slice exceeds stride");
+    SG_REQUIRE(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "srcgan_wgrad_dense: tensors must be 16-byte aligned");
+    for (int k = 0; k < d->nseg; ++k)
+        SG_REQUIRE(d->seg[k].g0 >= 0 && d->seg[k].g1 > d->seg[k].g0 && d->seg[k].g1 <= d->G && d->seg[k].Cin > 0 && d->seg[k].Cin <= d->C,
+                   "srcgan_wgrad_dense: bad segment %d", k);
+    hipStream_t st = (hipStream_t)stream;
+    // row groups of up to 128 gradient channels; per group only the Cin tiles some segment of the group needs
+    for (int g_base = 0; g_base < d->G; g_base += 128) {
+        const int rows = d->G - g_base < 128 ? d->G - g_base : 128;
+        const int mt = cdiv(rows, 32);
+        int cin_max = 0, want_bias = 0;
+        for (int k = 0; k < d->nseg; ++k)
+            if (d->seg[k].g0 < g_base + rows && d->seg[k].g1 > g_base) {
+                if (d->seg[k].grad && d->seg[k].Cin > cin_max) cin_max = d->seg[k].Cin;
+                if (d->seg[k].bias) want_bias = 1;
+            }
+        if (cin_max == 0 && !want_bias) continue;
+        if (cin_max == 0) cin_max = 1;                       // bias only: one Cin tile carries the pseudo-tap
+        WdP p;
+        memset(&p, 0, sizeof(p));
+        p.dy = d->dy; p.x = d->x; p.slab = d->slab;
+        p.B = d->B; p.H = d->H; p.W = d->W; p.G = d->G; p.C = d->C;
+        p.dyCs = d->dy_cs; p.dycoff = d->dy_coff; p.xCs = d->x_cs; p.xcoff = d->x_coff;
+        p.g_base = g_base; p.ncit = cdiv(cin_max, 64); p.want_bias = want_bias;
+        p.nsplit = wd_nsplit(mt, p.ncit, d->dtype, d->B, d->H, d->W);
+        int ns = 0;
+        if (d->dtype == SRCGAN_F32) SG_TRY(dispatch_wd<float>(p, mt, st, ns));
+        else SG_TRY(dispatch_wd<__bf16>(p, mt, st, ns));
+        WdRedP q;
+        memset(&q, 0, sizeof(q));
+        q.slab = d->slab; q.nsplit = ns; q.ncit = p.ncit; q.COT = 32 * mt; q.g_base = g_base; q.nseg = d->nseg; q.accumulate = d->accumulate;
+        for (int k = 0; k < d->nseg; ++k) { q.seg[k].g0 = d->seg[k].g0; q.seg[k].g1 = d->seg[k].g1; q.seg[k].grad = d->seg[k].grad;
+                                            q.seg[k].bias = d->seg[k].bias; q.seg[k].Cin = d->seg[k].Cin; q.seg[k].alpha = d->seg[k].alpha; }
+        const long per_split = (long)p.ncit * 10 * q.COT * 64;
+        hipLaunchKernelGGL(wgrad_dense_reduce_k<64>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
+        SG_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -116,6 +116,26 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, *, kh: int
     return grad
 
 
+def wgrad_dense(dy: torch.Tensor, x: torch.Tensor, segs, *, G: Optional[int] = None, Cc: Optional[int] = None) -> None:
+    """Dense-block weight gradient.  dy [B,H,W,>=G], x [B,H,W,>=C] NHWC; segs = [(g0, g1, grad|None, bias|None, Cin, alpha)]."""
+    N.require_cuda(x, "wgrad_dense")
+    lib = N.lib()
+    d = N.WgradDenseDesc()
+    B, H, W, dycs = dy.shape
+    G = G or dycs
+    Cc = Cc or x.shape[3]
+    dt = N.dtype_id(x.dtype)
+    slab = torch.empty(lib.srcgan_wgrad_dense_slab_bytes(G, Cc, dt, B, H, W), dtype=torch.uint8, device=x.device)
+    d.dy, d.x, d.slab, d.dtype = dy.data_ptr(), x.data_ptr(), slab.data_ptr(), dt
+    d.B, d.H, d.W, d.G, d.dy_cs, d.dy_coff, d.C, d.x_cs, d.x_coff = B, H, W, G, dycs, 0, Cc, x.shape[3], 0
+    d.nseg = len(segs)
+    for i, (g0, g1, grad, bias, cin, alpha) in enumerate(segs):
+        d.seg[i].g0, d.seg[i].g1, d.seg[i].Cin, d.seg[i].alpha = g0, g1, cin, alpha
+        d.seg[i].grad = grad.data_ptr() if grad is not None else None
+        d.seg[i].bias = bias.data_ptr() if bias is not None else None
+    N.check(lib.srcgan_wgrad_dense(C.byref(d), N.stream_ptr(x.device)), "srcgan_wgrad_dense")
+
+
 def col_sum(a: torch.Tensor, Cc: int, coff: int = 0, scale: float = 1.0) -> torch.Tensor:
     """sum over pixels of NHWC a[..., coff:coff+C] -> f32 [C] (bias gradient)."""
     N.require_cuda(a, "col_sum")

@@ -251,3 +251,35 @@ def test_preproc_golden(ops):
         assert rel_err(ops.nearest_resize(img, 1.0 / up).cpu(), g[f"near_down{up}"]) < 1e-6
     big = torch.rand(2, 3, 64, 96, device="cuda")
     assert rel_err(ops.nearest_resize(big, 2).cpu(), F.interpolate(big.cpu(), scale_factor=2)) < 1e-7
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("nf,gc,hw", [(64, 32, (20, 40)), (16, 8, (9, 33)), (32, 16, (16, 64))])
+def test_wgrad_dense_block(ops, dt, nf, gc, hw):
+    """One pass over (dense gradient buffer, dense activation buffer) = weight + bias gradients of all five RDB convs."""
+    torch.manual_seed(11)
+    H, W = hw
+    Cc = nf + 4 * gc
+    A = _q(torch.rand(2, Cc, H, W) - 0.5, dt)
+    Gd = _q(torch.rand(2, Cc, H, W) - 0.5, dt)          # [dy5 (nf) | dy4 | dy3 | dy2 | dy1]
+    segs, refs = [], []
+    for m in (5, 4, 3, 2, 1):
+        g0 = 0 if m == 5 else nf + (4 - m) * gc
+        co = nf if m == 5 else gc
+        cin = nf + (m - 1) * gc
+        alpha = 0.2 if m == 5 else 1.0
+        w = torch.zeros(co, cin, 3, 3, requires_grad=True)
+        b = torch.zeros(co, requires_grad=True)
+        F.conv2d(A[:, :cin], w, b, 1, 1).backward(Gd[:, g0:g0 + co] * alpha)
+        gw, gb = torch.full((co, cin, 3, 3), 7.0, device="cuda"), torch.full((co,), 7.0, device="cuda")
+        segs.append((g0, g0 + co, gw, gb, cin, alpha))
+        refs.append((w.grad, b.grad))
+    ops.wgrad_dense(_nhwc(ops, Gd, Cc, dt), _nhwc(ops, A, Cc, dt), segs)
+    for (g0, g1, gw, gb, cin, alpha), (rw, rb) in zip(segs, refs):
+        assert rel_err(gw.cpu(), rw) < TOL[dt], (g0, cin)
+        assert rel_err(gb.cpu(), rb) < TOL[dt], (g0, cin)
+    # frozen weights: only bias gradients requested
+    segs2 = [(g0, g1, None, torch.zeros_like(gb), cin, alpha) for (g0, g1, gw, gb, cin, alpha) in segs]
+    ops.wgrad_dense(_nhwc(ops, Gd, Cc, dt), _nhwc(ops, A, Cc, dt), segs2)
+    for (g0, g1, _, gb, cin, alpha), (rw, rb) in zip(segs2, refs):
+        assert rel_err(gb.cpu(), rb) < TOL[dt]
