@@ -92,6 +92,9 @@ typedef struct srcgan_conv_desc {
     int mz_cs, mz_coff, mz_c0;
     float alpha, beta1, beta2, slope, mslope;
     int act;
+    /* plane strides in BYTES for the blocked layout (0 = interleaved NHWC): channel c of pixel q lives at
+     * q*cs*esz + (c/KCE)*plane + (c%KCE)*esz with KCE = 64/esz channels; blocked tensors use cs = KCE. */
+    long x_plane, y_plane, r1_plane, r2_plane, mz_plane;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 
@@ -138,6 +141,7 @@ typedef struct srcgan_wgrad_dense_desc {
     int nseg;
     srcgan_wgrad_seg seg[8];
     int accumulate;
+    long dy_plane, x_plane;                 /* blocked-layout plane strides in bytes (0 = interleaved NHWC) */
 } srcgan_wgrad_dense_desc;
 size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, int H, int W);
 int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream);
@@ -172,6 +176,10 @@ int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mea
  * (residual gradient joins; optional LeakyReLU' of the tensor the gradient belongs to) */
 int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
                        const void* mz, int mz_cs, int mz_coff, float mslope, long npix, int C, int dtype, void* stream);
+/* same with blocked-layout plane strides (bytes, 0 = interleaved NHWC) for each tensor */
+int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const void* x, int x_cs, int x_coff, long x_plane,
+                              const void* mz, int mz_cs, int mz_coff, long mz_plane, float mslope, long npix, int C,
+                              int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Loss reductions on flat f32 arrays (replace aten::l1_loss / mse_loss and their

@@ -6,6 +6,7 @@ from srcgan_amd import ops
 
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
+blocked = os.environ.get("MB_BLOCKED") == "1"
 B, H, W = int(os.environ.get("MB_B", "16")), 256, 256
 tdt = torch.bfloat16 if dt == "bf16" else torch.float32
 torch.manual_seed(0)
@@ -23,7 +24,15 @@ if which in ("all", "igemm"):
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         wp = ops.pack_conv2d_fwd(w, dt)
         b = torch.zeros(cout, device="cuda")
-        if cin + cout <= 192:
+        if blocked and cin + cout <= 192:
+            db, pl = ops.make_blocked(dense)
+            f = lambda: ops.conv_igemm(db, wp, db, kh=3, kw=3, Cin=cin, Cout=cout, y_coff=cin, pad=(1, 1), bias=b, act=True,
+                                       x_plane=pl, y_plane=pl, shape=(B, H, W))
+        elif blocked:
+            db, pl = ops.make_blocked(dense)
+            f = lambda: ops.conv_igemm(db, wp, out64, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), bias=b, alpha=0.2, r1=db, r1_cend=64, beta1=1.0,
+                                       x_plane=pl, r1_plane=pl, shape=(B, H, W))
+        elif cin + cout <= 192:
             f = lambda: ops.conv_igemm(dense, wp, dense, kh=3, kw=3, Cin=cin, Cout=cout, y_coff=cin, pad=(1, 1), bias=b, act=True)
         else:
             f = lambda: ops.conv_igemm(dense, wp, out64, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), bias=b, alpha=0.2, r1=dense, r1_cend=64, beta1=1.0)

@@ -52,7 +52,8 @@ class ConvDesc(C.Structure):
                 ("r2_cs", C.c_int), ("r2_coff", C.c_int), ("r2_cend", C.c_int),
                 ("mz_cs", C.c_int), ("mz_coff", C.c_int), ("mz_c0", C.c_int),
                 ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("slope", C.c_float), ("mslope", C.c_float),
-                ("act", C.c_int)]
+                ("act", C.c_int),
+                ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long)]
 
 
 class WgradDesc(C.Structure):
@@ -74,7 +75,7 @@ class WgradDenseDesc(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("G", C.c_int), ("dy_cs", C.c_int), ("dy_coff", C.c_int),
                 ("C", C.c_int), ("x_cs", C.c_int), ("x_coff", C.c_int),
-                ("nseg", C.c_int), ("seg", WgradSeg * 8), ("accumulate", C.c_int)]
+                ("nseg", C.c_int), ("seg", WgradSeg * 8), ("accumulate", C.c_int), ("dy_plane", C.c_long), ("x_plane", C.c_long)]
 
 
 class RddbCfg(C.Structure):
@@ -112,6 +113,7 @@ SIGNATURES = {
     "srcgan_bn_apply_lrelu": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
     "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
+    "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
     "srcgan_loss_scratch_floats": (_I, []),
     "srcgan_loss_fwd": (_I, [_I, _P, _P, _F, _L, _P, _P, _P]),
     "srcgan_loss_bwd": (_I, [_I, _P, _P, _F, _L, _P, _F, _P, _P]),

@@ -22,8 +22,11 @@ static __device__ __attribute__((aligned(64))) unsigned int sg_zero_page[16];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int MT, int NWV, int NBUF, int PT>
-__global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
+// NLW > 0: wave specialisation -- NLW extra "loader" waves issue every LDS-DMA piece, the NWV MFMA waves never touch
+// VMEM inside the loop.  In the DMA-bound regime the issuing wave stalls in VMEM issue until the memory pipeline
+// accepts its pieces (measured: DMA-only 100 us + MFMA-only 92 us ran 154 us when the same waves did both).
+template <typename T, int MT, int NWV, int NBUF, int PT, int NLW>
+__global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p) {
     using D = DT<T>;
     static_assert(NBUF == 2, "persistent pipeline is double-buffered");
     constexpr int TH = PT * NWV, TW = 32, IHT = TH + 2, IWT = TW + 2;
@@ -32,12 +35,16 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
     constexpr int HPIECES = (NHP * 64 + 1023) / 1024;    // one-KiB DMA pieces (last one partly junk)
     constexpr int WPIECES = NTAP * COT * 64 / 1024;      // 36 (MT=2) / 18 (MT=1)
     constexpr int HBYTES = HPIECES * 1024, WBYTES = WPIECES * 1024, SBYTES = HBYTES + WBYTES;
-    constexpr int HIT = (HPIECES + NWV - 1) / NWV, WIT = (WPIECES + NWV - 1) / NWV;
+    constexpr int NIW = NLW ? NLW : NWV;                 // waves that issue DMA
+    constexpr int HIT = (HPIECES + NIW - 1) / NIW, WIT = (WPIECES + NIW - 1) / NIW;
     constexpr int ERS = COT * 4 + 16;                    // epilogue transpose row stride
     static_assert(NWV * 32 * ERS <= SBYTES, "epilogue transpose space must fit one stage");
     extern __shared__ __attribute__((aligned(1024))) char smem[];    // [stage0: halo | weights][stage1: halo | weights]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: role branches stay scalar
+    const bool loader = NLW > 0 && wave >= NWV;
+    const int iw = NLW ? wave - NWV : wave;              // index among the issuing waves
     // Persistent workgroups.  Units (spatial tile x Cout tile) are dealt so that the workgroups of one XCD
     // (blockIdx % 8) walk one contiguous range together: neighbouring halos / the Cout tiles of a tile share an L2.
     const int nunits = p.tiles_x * p.tiles_y * p.B * p.ctiles;
@@ -53,12 +60,12 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
     int h_goff[HIT], h_part[HIT], w_off[WIT];
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
-        const int q = (it * NWV + wave) * 64 + lane, lp = q >> 2;
+        const int q = (it * NIW + iw) * 64 + lane, lp = q >> 2;
         h_part[it] = (q & 3) ^ ((lp >> 2) & 3);
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
-        const int q = (it * NWV + wave) * 64 + lane, wr = q >> 2;
+        const int q = (it * NIW + iw) * 64 + lane, wr = q >> 2;
         w_off[it] = wr * 64 + (((q & 3) ^ ((wr >> 2) & 3)) * 16);
     }
     const char* f_xb = nullptr; const char* f_wb = nullptr;      // fetch-side base pointers
@@ -68,15 +75,15 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
         const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
         ob = b; oct = ct; ooy0 = ty * TH; oox0 = tx * TW;
         const int gy0 = ooy0 - p.pad_y, gx0 = oox0 - p.pad_x;
-        f_xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+        f_xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix;
         f_wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
-            const int q = (it * NWV + wave) * 64 + lane, lp = q >> 2;
+            const int q = (it * NIW + iw) * 64 + lane, lp = q >> 2;
             const int iy = lp / IWT, ix = lp - iy * IWT;
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = lp < NHP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            h_goff[it] = ok ? ((gy * p.W + gx) * p.xCs * (int)sizeof(T) + h_part[it] * 16) : -1;
+            h_goff[it] = ok ? (gy * p.W + gx) * (int)p.xpix : -1;
         }
     };
     auto issue = [&](int c, int stage) {
@@ -84,18 +91,19 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
         char* lw = lh + HBYTES;
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
-            const int pi = it * NWV + wave;
-            if (HIT * NWV == HPIECES || pi < HPIECES) {        // wave-uniform
-                const bool ok = h_goff[it] >= 0 && (c * D::KCE + h_part[it] * D::EPP < p.Cin);
-                const char* src = ok ? f_xb + h_goff[it] + c * 64 : zp;
+            const int pi = it * NIW + iw;
+            if (HIT * NIW == HPIECES || pi < HPIECES) {        // wave-uniform
+                const int chl = c * D::KCE + h_part[it] * D::EPP;          // channel within the conv's input slice
+                const bool ok = h_goff[it] >= 0 && chl < p.Cin;
+                const char* src = ok ? f_xb + h_goff[it] + chan_off<T>(p.xcoff + chl, p.xplane) : zp;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lh + pi * 1024), 16, 0, 0);
             }
         }
         const char* ws = f_wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int pi = it * NWV + wave;
-            if (WIT * NWV == WPIECES || pi < WPIECES)
+            const int pi = it * NIW + iw;
+            if (WIT * NIW == WPIECES || pi < WPIECES)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ws + w_off[it]), (lptr_t)(lw + pi * 1024), 16, 0, 0);
         }
     };
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
     int cb, cct, coy0, cox0;            // unit being computed
     int nb_, nct, noy0, nox0;           // unit being fetched
     setup_fetch(u, nb_, nct, noy0, nox0);
-    issue(0, 0);
+    if (NLW == 0 || loader) issue(0, 0);
     int stage = 0;
     for (; u < u_hi; u += gw) {
         cb = nb_; cct = nct; coy0 = noy0; cox0 = nox0;
@@ -120,9 +128,10 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
         for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
             __syncthreads();        // own DMAs into `stage` landed (vmcnt(0)); everyone is done with the other stage
             if (!(p.dbg & 2)) {
-                if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
-                else if (u + gw < u_hi) { setup_fetch(u + gw, nb_, nct, noy0, nox0); issue(0, stage ^ 1); }   // next unit's first chunk
+                if (c + 1 < p.nchunk) { if (NLW == 0 || loader) issue(c + 1, stage ^ 1); }
+                else if (u + gw < u_hi) { setup_fetch(u + gw, nb_, nct, noy0, nox0); if (NLW == 0 || loader) issue(0, stage ^ 1); }   // next unit's first chunk
             }
+            if (loader) continue;
             const char* lh = smem + stage * SBYTES;
             const char* lw = lh + HBYTES;
             if (p.dbg & 1) continue;
@@ -175,24 +184,25 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_dma_k(const ConvP p) {
         // ---- epilogue of the finished unit; the next unit's first chunk is already in flight into `stage`
         // (the loop increment flipped it), so the transpose space is the OTHER stage = the one just computed from.
         if (p.vec16) {
-            __syncthreads();      // every wave finished reading the last chunk before its stage is reused
+            __syncthreads();      // every wave finished reading the last chunk before its stage is reused (loaders join)
+            if (loader) continue;
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
 #pragma unroll
             for (int q = 0; q < PT; ++q)
                 conv_epilogue_lds_row<T, MT, PT>(p, acc, q, tsp, cb, cct, coy0 + wave * PT + q, cox0, lane);
-        } else {
+        } else if (!loader) {
             conv_epilogue<T, MT, PT>(p, acc, cb, cct, coy0 + wave * PT, cox0, r, h);
         }
     }
 }
 
-template <typename T, int MT, int NWV, int NBUF, int PT>
+template <typename T, int MT, int NWV, int NBUF, int PT, int NLW = 0>
 static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int TH = PT * NWV;
     constexpr int HB = (((TH + 2) * 34 * 64 + 1023) / 1024) * 1024, WB = 9 * 32 * MT * 64;
     constexpr size_t SMEM = NBUF * ((size_t)HB + (size_t)WB);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_dma_k<T, MT, NWV, NBUF, PT>;
+    auto kern = conv3x3_dma_k<T, MT, NWV, NBUF, PT, NLW>;
     static bool attr_set = false;
     if (!attr_set) {
         SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -210,16 +220,16 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
         SG_HIP(hipGetDevice(&dev)); SG_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount;
         wg_per_cu = (int)((160 * 1024) / SMEM); if (wg_per_cu < 1) wg_per_cu = 1;
-        if (wg_per_cu * NWV > 16) wg_per_cu = 16 / NWV;
+        if (wg_per_cu * (NWV + NLW) > 16) wg_per_cu = 16 / (NWV + NLW) > 0 ? 16 / (NWV + NLW) : 1;
     }
     size_t nwg = (size_t)ncu * wg_per_cu;
     if (nwg > nunits) nwg = nunits;
     dim3 grid((unsigned)nwg, 1, 1);
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_dma<%s,MT%d,W%d,B%d,PT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NWV, NBUF, PT);
+    snprintf(cls, sizeof(cls), "conv3x3_dma<%s,MT%d,W%d+%d,PT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NWV, NLW, PT);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
-    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), SMEM, st, q);
+    hipLaunchKernelGGL(kern, grid, dim3((NWV + NLW) * 64), SMEM, st, q);
     sg_prof_stop(tok, st);
     SG_LAUNCH_CHECK();
     return 0;
@@ -232,11 +242,13 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
     if (p.Cout <= 32) {
         if (cfg == 'b') return launch_dma<T, 1, 4, 2, 2>(p, 1, st);
         if (cfg == 'd') return launch_dma<T, 1, 4, 2, 4>(p, 1, st);
+        if (cfg == 'l') return launch_dma<T, 1, 8, 2, 2, 4>(p, 1, st);
         return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
     }
     const int ctiles = cdiv(p.Cout, 64);
     if (cfg == 'b') return launch_dma<T, 2, 4, 2, 2>(p, ctiles, st);
     if (cfg == 'd') return launch_dma<T, 2, 4, 2, 4>(p, ctiles, st);
+    if (cfg == 'l') return launch_dma<T, 2, 8, 2, 2, 4>(p, ctiles, st);
     return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
 }
 

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
-    const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+    const char* xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix + (size_t)p.xcoff * sizeof(T);
     const char* wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
 
     // ---- per-thread staging descriptors (independent of the channel chunk).  Loads are issued
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         const int iy = pix / IWT, ix = pix - iy * IWT;
         const int gy = gy0 + iy, gx = gx0 + ix;
         const bool ok = pc < NPH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        h_goff[it] = ok ? ((gy * p.W + gx) * p.xCs * (int)sizeof(T) + part * 16) : -1;
+        h_goff[it] = ok ? ((gy * p.W + gx) * (int)p.xpix + part * 16) : -1;
     }
     u32x4 hreg[HIT];
     u32x4 wreg[WPK ? 1 : WIT];
@@ -238,8 +238,6 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
 }
 
 int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st);      // conv3x3_dma.hip
-int sg_conv3x3_pipe(const ConvP& p, int dtype, hipStream_t st);     // conv3x3_pipe.hip
-static const bool g_use_pipe = getenv("SRCGAN_PIPE") != nullptr;
 static const bool g_force_generic = getenv("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
 
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
@@ -251,19 +249,25 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                "srcgan_conv_igemm: non-positive dimension");
     SG_REQUIRE(d->Cin % epp == 0 && d->x_cs % epp == 0 && d->x_coff % epp == 0,
                "srcgan_conv_igemm: input channels/stride/offset (%d,%d,%d) must be multiples of %d", d->Cin, d->x_cs, d->x_coff, epp);
-    SG_REQUIRE(d->x_coff + d->Cin <= d->x_cs && d->y_coff + d->Cout <= d->y_cs, "srcgan_conv_igemm: channel slice exceeds stride");
+    SG_REQUIRE((d->x_plane || d->x_coff + d->Cin <= d->x_cs) && (d->y_plane || d->y_coff + d->Cout <= d->y_cs),
+               "srcgan_conv_igemm: channel slice exceeds stride");
+    SG_REQUIRE(!d->x_plane || (d->kh == 3 && d->kw == 3 && d->stride == 1), "srcgan_conv_igemm: a blocked-layout input is supported by the 3x3 stride-1 kernel only");
     SG_REQUIRE(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->wp % 16) == 0, "srcgan_conv_igemm: x/wp must be 16-byte aligned");
     SG_REQUIRE(d->os >= 1 && d->oa >= 0 && d->ob >= 0 && d->oa < d->os && d->ob < d->os, "srcgan_conv_igemm: bad output scale/offset");
     SG_REQUIRE((d->OH - 1) * d->os + d->oa < d->YH && (d->OW - 1) * d->os + d->ob < d->YW, "srcgan_conv_igemm: output extent exceeds tensor");
     ConvP p;
     memset(&p, 0, sizeof(p));
     p.x = d->x; p.wp = d->wp; p.bias = d->bias; p.y = d->y; p.r1 = d->r1; p.r2 = d->r2; p.mz = d->mz;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xCs = d->x_cs; p.xcoff = d->x_coff;
-    p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.YH = d->YH; p.YW = d->YW; p.yCs = d->y_cs; p.ycoff = d->y_coff;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xcoff = d->x_coff;
+    p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.YH = d->YH; p.YW = d->YW; p.ycoff = d->y_coff;
     p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.os = d->os; p.oa = d->oa; p.ob = d->ob;
-    p.r1Cs = d->r1_cs; p.r1coff = d->r1_coff; p.r1cend = d->r1_cend;
-    p.r2Cs = d->r2_cs; p.r2coff = d->r2_coff; p.r2cend = d->r2_cend;
-    p.mzCs = d->mz_cs; p.mzcoff = d->mz_coff; p.mzc0 = d->mz_c0;
+    p.r1coff = d->r1_coff; p.r1cend = d->r1_cend;
+    p.r2coff = d->r2_coff; p.r2cend = d->r2_cend;
+    p.mzcoff = d->mz_coff; p.mzc0 = d->mz_c0;
+    auto pl = [](long v) { return v ? v : 64L; };      // plane stride 0 = interleaved NHWC
+    p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * esz; p.yplane = pl(d->y_plane);
+    p.r1pix = (long)d->r1_cs * esz; p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
+    p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
     p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
     p.act = d->act;
     const int kce = 64 / esz;
@@ -282,7 +286,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && !g_force_generic) return g_use_pipe ? sg_conv3x3_pipe(p, d->dtype, st) : sg_conv3x3_dma(p, d->dtype, st);
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane)) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);

@@ -2,18 +2,29 @@
 #pragma once
 #include "common.h"
 
+// Tensor addressing: byte offset of channel c of pixel index q = q*pix + (c / KCE)*plane + (c % KCE)*sizeof(T), KCE = the
+// 64-byte channel chunk.  Interleaved NHWC is pix = Cs*sizeof(T), plane = 64; the "blocked" layout used for the
+// dense-block buffers is pix = 64, plane = npixels*64 (each 64-byte chunk of every pixel contiguous across pixels:
+// operand fetches become >=128-byte contiguous; measured 3.4 TB/s -> 6.7 TB/s LDS-DMA ingest, scripts/hip/dma_stream_test.hip).
 struct ConvP {
     const void* x; const void* wp; const float* bias; void* y;
     const void* r1; const void* r2; const void* mz;
-    int B, H, W, Cin, xCs, xcoff;
-    int OH, OW, Cout, YH, YW, yCs, ycoff;
+    int B, H, W, Cin, xcoff;
+    int OH, OW, Cout, YH, YW, ycoff;
     int pad_y, pad_x, os, oa, ob;
-    int r1Cs, r1coff, r1cend, r2Cs, r2coff, r2cend, mzCs, mzcoff, mzc0;
+    int r1coff, r1cend, r2coff, r2cend, mzcoff, mzc0;
+    long xpix, xplane, ypix, yplane, r1pix, r1plane, r2pix, r2plane, mzpix, mzplane;     // bytes
     float alpha, beta1, beta2, slope, mslope;
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
 };
+
+template <typename T>
+__device__ __forceinline__ size_t chan_off(int c, long plane) {        // byte offset of channel c inside a pixel record
+    constexpr int KCE = DT<T>::KCE;
+    return (size_t)(c / KCE) * plane + (size_t)(c % KCE) * sizeof(T);
+}
 
 // Fused epilogue for a 32x32 MFMA result tile set.  acc[m][q][4g+i] = D[cout = 32m + 8g + 4h + i][pixel = r]
 // (M = Cout, N = 32 consecutive output pixels of row oyb+q): each lane owns 4 consecutive channels of one pixel.
@@ -29,10 +40,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
         const int oy = oyb + q;
         if (oy >= p.OH || ox >= p.OW) continue;
         const size_t opix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + (size_t)ox * p.os + p.ob;
-        T* yp = (T*)p.y + opix * p.yCs + p.ycoff;
-        const T* r1p = p.r1 ? (const T*)p.r1 + opix * p.r1Cs + p.r1coff : nullptr;
-        const T* r2p = p.r2 ? (const T*)p.r2 + opix * p.r2Cs + p.r2coff : nullptr;
-        const T* mzp = p.mz ? (const T*)p.mz + opix * p.mzCs + p.mzcoff : nullptr;
+        char* yp = (char*)p.y + opix * p.ypix;
+        const char* r1p = p.r1 ? (const char*)p.r1 + opix * p.r1pix : nullptr;
+        const char* r2p = p.r2 ? (const char*)p.r2 + opix * p.r2pix : nullptr;
+        const char* mzp = p.mz ? (const char*)p.mz + opix * p.mzpix : nullptr;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -48,19 +59,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                         for (int i = 0; i < 4; ++i) v[i] += bv[i]; }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
-                    if (r1p && co0 < p.r1cend) { float rv[4]; load4<T>(r1p + co0, rv);
+                    if (r1p && co0 < p.r1cend) { float rv[4]; load4<T>((const T*)(r1p + chan_off<T>(p.r1coff + co0, p.r1plane)), rv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += p.beta1 * rv[i]; }
-                    if (r2p && co0 < p.r2cend) { float rv[4]; load4<T>(r2p + co0, rv);
+                    if (r2p && co0 < p.r2cend) { float rv[4]; load4<T>((const T*)(r2p + chan_off<T>(p.r2coff + co0, p.r2plane)), rv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += p.beta2 * rv[i]; }
                     if (p.act) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-                    if (mzp && co0 >= p.mzc0) { float zv[4]; load4<T>(mzp + co0, zv);
+                    if (mzp && co0 >= p.mzc0) { float zv[4]; load4<T>((const T*)(mzp + chan_off<T>(p.mzcoff + co0, p.mzplane)), zv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] *= (zv[i] > 0.f ? 1.f : p.mslope); }
-                    store4<T>(yp + co0, v);
+                    store4<T>((T*)(yp + chan_off<T>(p.ycoff + co0, p.yplane)), v);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -69,11 +80,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                         float u = v[i];
                         if (p.bias) u += p.bias[co];
                         u *= p.alpha;
-                        if (r1p && co < p.r1cend) u += p.beta1 * to_f(r1p[co]);
-                        if (r2p && co < p.r2cend) u += p.beta2 * to_f(r2p[co]);
+                        if (r1p && co < p.r1cend) u += p.beta1 * to_f(*(const T*)(r1p + chan_off<T>(p.r1coff + co, p.r1plane)));
+                        if (r2p && co < p.r2cend) u += p.beta2 * to_f(*(const T*)(r2p + chan_off<T>(p.r2coff + co, p.r2plane)));
                         if (p.act) u = u > 0.f ? u : u * p.slope;
-                        if (mzp && co >= p.mzc0) u *= (to_f(mzp[co]) > 0.f ? 1.f : p.mslope);
-                        yp[co] = from_f<T>(u);
+                        if (mzp && co >= p.mzc0) u *= (to_f(*(const T*)(mzp + chan_off<T>(p.mzcoff + co, p.mzplane))) > 0.f ? 1.f : p.mslope);
+                        *(T*)(yp + chan_off<T>(p.ycoff + co, p.yplane)) = from_f<T>(u);
                     }
                 }
             }
@@ -127,22 +138,22 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, const f32x16 (
         typedef __attribute__((ext_vector_type(EPP))) T vecT;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (use_r1) { const vecT t = *(const vecT*)((const T*)p.r1 + opix * p.r1Cs + p.r1coff + co0);
+        if (use_r1) { const vecT t = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
-        if (use_r2) { const vecT t = *(const vecT*)((const T*)p.r2 + opix * p.r2Cs + p.r2coff + co0);
+        if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + opix * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (use_mz) { const vecT t = *(const vecT*)((const T*)p.mz + opix * p.mzCs + p.mzcoff + co0);
+        if (use_mz) { const vecT t = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] *= (to_f(t[i]) > 0.f ? 1.f : p.mslope); }
         vecT o;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
-        *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
+        *(vecT*)((char*)p.y + opix * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane)) = o;
     }
     // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
     // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
@@ -190,22 +201,22 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         typedef __attribute__((ext_vector_type(EPP))) T vecT;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (use_r1) { const vecT t = *(const vecT*)((const T*)p.r1 + opix * p.r1Cs + p.r1coff + co0);
+        if (use_r1) { const vecT t = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
-        if (use_r2) { const vecT t = *(const vecT*)((const T*)p.r2 + opix * p.r2Cs + p.r2coff + co0);
+        if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + opix * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (use_mz) { const vecT t = *(const vecT*)((const T*)p.mz + opix * p.mzCs + p.mzcoff + co0);
+        if (use_mz) { const vecT t = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] *= (to_f(t[i]) > 0.f ? 1.f : p.mslope); }
         vecT o;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
-        *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
+        *(vecT*)((char*)p.y + opix * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane)) = o;
     }
     // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
     // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
@@ -261,22 +272,22 @@ __device__ __forceinline__ void conv_epilogue_lds_half(const ConvP& p, const f32
         typedef __attribute__((ext_vector_type(EPP))) T vecT;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (use_r1) { const vecT t = *(const vecT*)((const T*)p.r1 + opix * p.r1Cs + p.r1coff + co0);
+        if (use_r1) { const vecT t = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
-        if (use_r2) { const vecT t = *(const vecT*)((const T*)p.r2 + opix * p.r2Cs + p.r2coff + co0);
+        if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + opix * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (use_mz) { const vecT t = *(const vecT*)((const T*)p.mz + opix * p.mzCs + p.mzcoff + co0);
+        if (use_mz) { const vecT t = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] *= (to_f(t[i]) > 0.f ? 1.f : p.mslope); }
         vecT o;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
-        *(vecT*)((T*)p.y + opix * p.yCs + p.ycoff + co0) = o;
+        *(vecT*)((char*)p.y + opix * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane)) = o;
     }
     // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
     // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it

@@ -480,38 +480,53 @@ extern "C" int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const
 
 // --------------------------------------------------------------------------- residual-gradient join
 template <typename T>
-__global__ __launch_bounds__(256) void add_inplace_k(T* __restrict__ y, int yCs, int ycoff, const T* __restrict__ x, int xCs,
-                                                     int xcoff, const T* __restrict__ mz, int mzCs, int mzcoff, float mslope,
-                                                     long npix, int C4) {
+__device__ __forceinline__ size_t ew_chan_off(int c, long plane) {
+    constexpr int KCE = DT<T>::KCE;
+    return (size_t)(c / KCE) * plane + (size_t)(c % KCE) * sizeof(T);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_k(char* __restrict__ y, long ypix, long yplane, int ycoff, const char* __restrict__ x,
+                                                     long xpix, long xplane, int xcoff, const char* __restrict__ mz, long mzpix,
+                                                     long mzplane, int mzcoff, float mslope, long npix, int C4) {
     const long total = npix * C4;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long px = e / C4; const int c = (int)(e % C4) * 4;
+        T* yp = (T*)(y + px * ypix + ew_chan_off<T>(ycoff + c, yplane));
         float a[4], b[4];
-        load4<T>(y + (size_t)px * yCs + ycoff + c, a);
-        load4<T>(x + (size_t)px * xCs + xcoff + c, b);
+        load4<T>(yp, a);
+        load4<T>((const T*)(x + px * xpix + ew_chan_off<T>(xcoff + c, xplane)), b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] += b[i];
         if (mz) {
             float z[4];
-            load4<T>(mz + (size_t)px * mzCs + mzcoff + c, z);
+            load4<T>((const T*)(mz + px * mzpix + ew_chan_off<T>(mzcoff + c, mzplane)), z);
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] *= (z[i] > 0.f ? 1.f : mslope);
         }
-        store4<T>(y + (size_t)px * yCs + ycoff + c, a);
+        store4<T>(yp, a);
     }
 }
 
-extern "C" int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
-                                  const void* mz, int mz_cs, int mz_coff, float mslope, long npix, int C, int dtype, void* stream) {
+extern "C" int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const void* x, int x_cs, int x_coff, long x_plane,
+                                         const void* mz, int mz_cs, int mz_coff, long mz_plane, float mslope, long npix, int C,
+                                         int dtype, void* stream) {
     SG_REQUIRE(y && x && npix > 0 && C > 0, "srcgan_add_inplace: bad arguments");
     SG_REQUIRE(C % 4 == 0 && y_cs % 4 == 0 && y_coff % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 &&
                (!mz || (mz_cs % 4 == 0 && mz_coff % 4 == 0)),
                "srcgan_add_inplace: channel counts/strides/offsets must be multiples of 4");
+    const int esz = dtype == SRCGAN_F32 ? 4 : 2;
+    auto pl = [](long v) { return v ? v : 64L; };
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_inplace_k<T>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                                             (T*)y, y_cs, y_coff, (const T*)x, x_cs, x_coff, (const T*)mz, mz_cs, mz_coff, mslope,
-                                             npix, C / 4));
+                                             (char*)y, (long)y_cs * esz, pl(y_plane), y_coff, (const char*)x, (long)x_cs * esz, pl(x_plane), x_coff,
+                                             (const char*)mz, (long)mz_cs * esz, pl(mz_plane), mz_coff, mslope, npix, C / 4));
     SG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
+                                  const void* mz, int mz_cs, int mz_coff, float mslope, long npix, int C, int dtype, void* stream) {
+    return srcgan_add_inplace_planes(y, y_cs, y_coff, 0, x, x_cs, x_coff, 0, mz, mz_cs, mz_coff, 0, mslope, npix, C, dtype, stream);
 }
 
 // --------------------------------------------------------------------------- losses

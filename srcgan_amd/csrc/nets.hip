@@ -19,10 +19,10 @@
 
 namespace {
 
-struct TRef { void* p; int cs; int coff; };
-static inline TRef tref(void* p, int cs, int coff = 0) { return TRef{p, cs, coff}; }
-static inline TRef sl(TRef t, int coff) { return TRef{t.p, t.cs, t.coff + coff}; }
-static const TRef TNULL = {nullptr, 0, 0};
+struct TRef { void* p; int cs; int coff; long plane; };     // plane: blocked-layout plane stride in bytes (0 = NHWC)
+static inline TRef tref(void* p, int cs, int coff = 0, long plane = 0) { return TRef{p, cs, coff, plane}; }
+static inline TRef sl(TRef t, int coff) { return TRef{t.p, t.cs, t.coff + coff, t.plane}; }
+static const TRef TNULL = {nullptr, 0, 0, 0};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 static inline int img_cs(int c) { return round_up(c, 8); }     // image-like tensors: channels padded to 8
@@ -34,16 +34,16 @@ struct Conv {
         d.dtype = dtype; d.kh = kh; d.kw = kw; d.stride = stride;
         d.os = 1; d.alpha = 1.f; d.slope = 0.2f; d.mslope = 0.2f;
     }
-    Conv& in(TRef x, int B, int H, int W, int Cin) { d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.B = B; d.H = H; d.W = W; d.Cin = Cin; return *this; }
+    Conv& in(TRef x, int B, int H, int W, int Cin) { d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.x_plane = x.plane; d.B = B; d.H = H; d.W = W; d.Cin = Cin; return *this; }
     Conv& w(const void* wp, const float* bias = nullptr) { d.wp = wp; d.bias = bias; return *this; }
-    Conv& out(TRef y, int OH, int OW, int Cout) { d.y = y.p; d.y_cs = y.cs; d.y_coff = y.coff; d.OH = OH; d.OW = OW; d.Cout = Cout; d.YH = OH; d.YW = OW; return *this; }
+    Conv& out(TRef y, int OH, int OW, int Cout) { d.y = y.p; d.y_cs = y.cs; d.y_coff = y.coff; d.y_plane = y.plane; d.OH = OH; d.OW = OW; d.Cout = Cout; d.YH = OH; d.YW = OW; return *this; }
     Conv& pad(int py, int px) { d.pad_y = py; d.pad_x = px; return *this; }
     Conv& scatter(int os, int oa, int ob, int YH, int YW) { d.os = os; d.oa = oa; d.ob = ob; d.YH = YH; d.YW = YW; return *this; }
     Conv& alpha(float a) { d.alpha = a; return *this; }
-    Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_cend = cend; d.beta1 = beta; return *this; }
-    Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_cend = cend; d.beta2 = beta; return *this; }
+    Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_plane = r.plane; d.r1_cend = cend; d.beta1 = beta; return *this; }
+    Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_plane = r.plane; d.r2_cend = cend; d.beta2 = beta; return *this; }
     Conv& lrelu() { d.act = 1; return *this; }
-    Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_c0 = c0; return *this; }
+    Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
     int run(void* st) { return srcgan_conv_igemm(&d, st); }
 };
 
@@ -116,7 +116,7 @@ struct PackList {
 
 // ======================================================================================== RDDBNet
 struct RddbPlan {
-    int dtype, esz, nf, gc, nb, C, nst, ndn;
+    int dtype, esz, nf, gc, nb, C, nst, ndn, kce, nplane; long plane_bytes;
     int B, H, W;           // input
     int Ht, Wt;            // trunk resolution
     int HO, WO;            // output resolution
@@ -158,7 +158,10 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     P.xin = b.take(B * c->H * c->W * P.in_cs * e);
     P.fea0 = P.ndn ? b.take(B * c->H * c->W * c->nf * e) : 0;     // conv_first output at HR (HR->LR variant only)
     for (int s = 0; s < P.ndn; ++s) P.dn[s] = b.take(B * (c->H >> (s + 1)) * (c->W >> (s + 1)) * c->nf * e);
-    P.szA = align_up(B * P.Ht * P.Wt * P.C * e, 256);
+    // dense buffers use the blocked layout [plane = 64-byte channel chunk][pixel][64 B]: every operand fetch of the 3x3 kernel
+    // and of the dense wgrad is then >= 1 KiB contiguous (64-byte pieces at a 384-byte pixel stride ran at half rate)
+    P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
+    P.szA = align_up((size_t)P.nplane * P.plane_bytes, 256);
     P.A = b.take(P.szA * 3 * c->nb);
     P.T = b.take(B * P.Ht * P.Wt * c->nf * e);
     for (int s = 0; s <= P.nst; ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
@@ -211,7 +214,7 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     Q.dout = b.take(B * P.HO * P.WO * P.out_cs * e);
     for (int s = 0; s <= P.nst; ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
     Q.dT = b.take(B * P.Ht * P.Wt * c->nf * e);
-    Q.szP = B * P.Ht * P.Wt * P.C * e;
+    Q.szP = align_up((size_t)P.nplane * P.plane_bytes, 256);
     for (int i = 0; i < 3; ++i) Q.Pg[i] = b.take(Q.szP);
     for (int s = 0; s <= P.ndn; ++s) Q.dfea_dn[s] = b.take(B * (c->H >> s) * (c->W >> s) * c->nf * e);
     Q.dxin = b.take(B * c->H * c->W * P.in_cs * e);
@@ -246,7 +249,7 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
     char* w8 = (char*)ws;
     char* wp = w8 + P.wpk;
     auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
-    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.C); };
+    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.kce, 0, P.plane_bytes); };
 
     // ---- pack weights for this call (f32 canonical -> dtype, MFMA-friendly): ONE batched launch
     PackList packs(dt, wp);
@@ -333,7 +336,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr);
     auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
     auto S_ = [&](size_t off, int cs) { return tref(s8 + off, cs); };
-    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.C); };
+    auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.kce, 0, P.plane_bytes); };
     auto G = [&](int idx) { return grads[idx]; };
     const long npix_t = (long)B * H * W;
 
@@ -406,7 +409,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     // dense buffer.  Slice j of the block input gets its gradient from ONE conv over the channel prefix holding
     // dy5..dy_{j+1} (composite transposed weights), so every gradient element is written exactly once: no
     // read-modify-write accumulation, and the same prefix-read / slice-write pattern as forward.
-    auto Pg = [&](int g) { return tref(s8 + Q.Pg[g], P.C); };
+    auto Pg = [&](int g) { return tref(s8 + Q.Pg[g], P.kce, 0, P.plane_bytes); };
     SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(Pg(0), H, W, nf).pad(1, 1).run(st));
     (void)dT;
     for (int i = c->nb - 1; i >= 0; --i) {
@@ -434,8 +437,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             {
                 srcgan_wgrad_dense_desc wd;
                 memset(&wd, 0, sizeof(wd));
-                wd.dy = Gd.p; wd.dy_cs = Gd.cs; wd.dy_coff = Gd.coff; wd.G = P.C;
-                wd.x = A.p; wd.x_cs = A.cs; wd.x_coff = A.coff; wd.C = P.C;
+                wd.dy = Gd.p; wd.dy_cs = Gd.cs; wd.dy_coff = Gd.coff; wd.dy_plane = Gd.plane; wd.G = P.C;
+                wd.x = A.p; wd.x_cs = A.cs; wd.x_coff = A.coff; wd.x_plane = A.plane; wd.C = P.C;
                 wd.slab = slab; wd.dtype = dt; wd.B = B; wd.H = H; wd.W = W;
                 bool any = false;
                 for (int m = 5; m >= 1; --m) {
@@ -453,9 +456,9 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     // gradient w.r.t. the trunk input feature = dcur + dU0 (global skip); for the HR->LR variant the trunk input
     // is a LeakyReLU output, so its derivative is applied in the same pass.
     TRef trunk_in = Abuf(0);
-    SG_TRY(srcgan_add_inplace(dcur.p, dcur.cs, dcur.coff, dU0.p, dU0.cs, dU0.coff, P.ndn ? trunk_in.p : nullptr, trunk_in.cs, 0, 0.2f,
-                              npix_t, nf, dt, st));
-    TRef dfea = dcur;
+    SG_TRY(srcgan_add_inplace_planes(dU0.p, dU0.cs, dU0.coff, dU0.plane, dcur.p, dcur.cs, dcur.coff, dcur.plane,
+                                     P.ndn ? trunk_in.p : nullptr, trunk_in.cs, 0, trunk_in.plane, 0.2f, npix_t, nf, dt, st));
+    TRef dfea = dU0;             // (dU0 is not needed any more: the join is accumulated into it, NHWC)
     for (int s = P.ndn - 1; s >= 0; --s) {     // 3x3 s2 p1 stages of RDDBNetA, last to first
         const int hi = c->H >> s, wi = c->W >> s, ho = hi / 2, wo = wi / 2;
         TRef xin_s = s == 0 ? T_(P.fea0, nf) : T_(P.dn[s - 1], nf);

@@ -15,7 +15,8 @@
 struct WdSeg { int g0, g1; float* grad; float* bias; int Cin; float alpha; };
 struct WdP {
     const void* dy; const void* x; float* slab;
-    int B, H, W, G, C, dyCs, dycoff, xCs, xcoff;
+    int B, H, W, G, C, dycoff, xcoff;
+    long dypix, dyplane, xpix, xplane;       // bytes; see conv_params.h (interleaved NHWC: plane = 64)
     int g_base;                 // first gradient channel of this launch's row group
     int nsplit, tiles_x, tiles_y, ntiles, ncit, want_bias;
 };
@@ -33,6 +34,11 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p0, const char* p1) {
 }
 
 static __device__ __attribute__((aligned(64))) unsigned int wd_zero_page[16];
+template <typename T>
+__device__ __forceinline__ size_t wd_chan_off(int c, long plane) {
+    constexpr int KCE = DT<T>::KCE;
+    return (size_t)(c / KCE) * plane + (size_t)(c % KCE) * sizeof(T);
+}
 typedef const __attribute__((address_space(1))) void* wd_gptr_t;
 typedef __attribute__((address_space(3))) void* wd_lptr_t;
 
@@ -72,8 +78,8 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
         const int ty = q % p.tiles_y;
         const int b = q / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        const char* dyb = (const char*)p.dy + ((size_t)b * p.H * p.W * p.dyCs + p.dycoff) * sizeof(T);
-        const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.xCs + p.xcoff) * sizeof(T);
+        const char* dyb = (const char*)p.dy + (size_t)b * p.H * p.W * p.dypix;
+        const char* xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix;
         char* ls = smem + stage * SBYTES;
 #pragma unroll
         for (int it = 0; it < IPW; ++it) {
@@ -85,14 +91,15 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
                 const int m = pi / DPP, pix = (pi - m * DPP) * PXP + lpx;
                 const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
                 const int ch = p.g_base + m * 32 + part * D::EPP;
-                if (pix < DPX && oy < p.H && ox < p.W && ch < p.G) src = dyb + ((size_t)(oy * p.W + ox) * p.dyCs + ch) * sizeof(T);
+                if (pix < DPX && oy < p.H && ox < p.W && ch < p.G)
+                    src = dyb + (size_t)(oy * p.W + ox) * p.dypix + wd_chan_off<T>(p.dycoff + ch, p.dyplane);
             } else {
                 const int pj = pi - MT * DPP, n = pj / XPP, pix = (pj - n * XPP) * PXP + lpx;
                 const int iy = pix / IWT, ix = pix - iy * IWT;
                 const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
                 const int ch = (cit * NT + n) * 32 + part * D::EPP;
                 if (pix < XPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ch < p.C)
-                    src = xb + ((size_t)(gy * p.W + gx) * p.xCs + ch) * sizeof(T);
+                    src = xb + (size_t)(gy * p.W + gx) * p.xpix + wd_chan_off<T>(p.xcoff + ch, p.xplane);
             }
             __builtin_amdgcn_global_load_lds((wd_gptr_t)src, (wd_lptr_t)(ls + pi * 1024), 16, 0, 0);
         }
@@ -265,7 +272,7 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
                "srcgan_wgrad_dense: bad dimensions");
     SG_REQUIRE(d->G % epp == 0 && d->C % epp == 0 && d->dy_cs % epp == 0 && d->dy_coff % epp == 0 && d->x_cs % epp == 0 && d->x_coff % epp == 0,
                "srcgan_wgrad_dense: channel counts/strides/offsets must be multiples of %d", epp);
-    SG_REQUIRE(d->dy_coff + d->G <= d->dy_cs && d->x_coff + d->C <= d->x_cs, "srcgan_wgrad_dense: channel slice exceeds stride");
+    SG_REQUIRE((d->dy_plane || d->dy_coff + d->G <= d->dy_cs) && (d->x_plane || d->x_coff + d->C <= d->x_cs), "srcgan_wgrad_dense: channel slice exceeds stride");
     SG_REQUIRE(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "srcgan_wgrad_dense: tensors must be 16-byte aligned");
     for (int k = 0; k < d->nseg; ++k)
         SG_REQUIRE(d->seg[k].g0 >= 0 && d->seg[k].g1 > d->seg[k].g0 && d->seg[k].g1 <= d->G && d->seg[k].Cin > 0 && d->seg[k].Cin <= d->C,
@@ -287,7 +294,8 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
         memset(&p, 0, sizeof(p));
         p.dy = d->dy; p.x = d->x; p.slab = d->slab;
         p.B = d->B; p.H = d->H; p.W = d->W; p.G = d->G; p.C = d->C;
-        p.dyCs = d->dy_cs; p.dycoff = d->dy_coff; p.xCs = d->x_cs; p.xcoff = d->x_coff;
+        p.dycoff = d->dy_coff; p.xcoff = d->x_coff;
+        p.dypix = (long)d->dy_cs * esz; p.dyplane = d->dy_plane ? d->dy_plane : 64; p.xpix = (long)d->x_cs * esz; p.xplane = d->x_plane ? d->x_plane : 64;
         p.g_base = g_base; p.ncit = cdiv(cin_max, 64); p.want_bias = want_bias;
         p.nsplit = wd_nsplit(mt, p.ncit, d->dtype, d->B, d->H, d->W);
         int ns = 0;

@@ -36,6 +36,23 @@ def to_nchw(x: torch.Tensor, Cc: Optional[int] = None, coff: int = 0) -> torch.T
     return out
 
 
+def make_blocked(x_nhwc: torch.Tensor):
+    """NHWC [B,H,W,C] -> blocked [planes,B,H,W,KCE] (KCE = 64 bytes of channels), plus the plane stride in bytes."""
+    B, H, W, Cc = x_nhwc.shape
+    kce = 64 // x_nhwc.element_size()
+    npl = (Cc + kce - 1) // kce
+    out = torch.zeros(npl, B, H, W, kce, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    for pl in range(npl):
+        n = min(kce, Cc - pl * kce)
+        out[pl, ..., :n] = x_nhwc[..., pl * kce:pl * kce + n]
+    return out, B * H * W * 64
+
+
+def from_blocked(xb: torch.Tensor, Cc: int) -> torch.Tensor:
+    npl, B, H, W, kce = xb.shape
+    return xb.permute(1, 2, 3, 0, 4).reshape(B, H, W, npl * kce)[..., :Cc].contiguous()
+
+
 def pack_weight(w: torch.Tensor, rows: int, kdim: int, tys: int, txs: int, sr: int, sk: int, sty: int, stx: int,
                 off: int = 0, dtype=None) -> torch.Tensor:
     N.require_cuda(w, "pack_weight")
@@ -64,11 +81,16 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
                slope: float = 0.2, r1: Optional[torch.Tensor] = None, r1_coff: int = 0, r1_cend: int = 0, beta1: float = 0.0,
                r2: Optional[torch.Tensor] = None, r2_coff: int = 0, r2_cend: int = 0, beta2: float = 0.0,
                mz: Optional[torch.Tensor] = None, mz_coff: int = 0, mz_c0: int = 0, mslope: float = 0.2,
-               os: int = 1, oa: int = 0, ob: int = 0) -> torch.Tensor:
-    """x, y, r1, r2, mz: NHWC tensors [B,H,W,cs] of the compute dtype.  Writes into y (returned)."""
+               os: int = 1, oa: int = 0, ob: int = 0, x_plane: int = 0, y_plane: int = 0, r1_plane: int = 0, r2_plane: int = 0,
+               mz_plane: int = 0, shape: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """x, y, r1, r2, mz: NHWC tensors [B,H,W,cs] of the compute dtype.  Writes into y (returned).
+    Blocked-layout tensors ([planes,B,H,W,KCE], see make_blocked) pass *_plane = plane stride in bytes and shape=(B,H,W)."""
     N.require_cuda(x, "conv_igemm")
     d = N.ConvDesc()
-    B, H, W, xcs = x.shape
+    if shape is not None:
+        (B, H, W), xcs = shape, x.shape[-1]
+    else:
+        B, H, W, xcs = x.shape
     d.x, d.wp, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.dtype = N.dtype_id(x.dtype)
@@ -78,15 +100,16 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
         OH = (H + 2 * pad[0] - kh) // stride + 1
         OW = (W + 2 * pad[1] - kw) // stride + 1
     d.OH, d.OW, d.Cout = OH, OW, Cout
-    d.YH, d.YW, d.y_cs, d.y_coff = y.shape[1], y.shape[2], y.shape[3], y_coff
+    d.YH, d.YW, d.y_cs, d.y_coff = (y.shape[-3], y.shape[-2], y.shape[-1], y_coff)
     d.pad_y, d.pad_x, d.os, d.oa, d.ob = pad[0], pad[1], os, oa, ob
     if r1 is not None:
-        d.r1, d.r1_cs, d.r1_coff, d.r1_cend, d.beta1 = r1.data_ptr(), r1.shape[3], r1_coff, r1_cend, beta1
+        d.r1, d.r1_cs, d.r1_coff, d.r1_cend, d.beta1 = r1.data_ptr(), r1.shape[-1], r1_coff, r1_cend, beta1
     if r2 is not None:
-        d.r2, d.r2_cs, d.r2_coff, d.r2_cend, d.beta2 = r2.data_ptr(), r2.shape[3], r2_coff, r2_cend, beta2
+        d.r2, d.r2_cs, d.r2_coff, d.r2_cend, d.beta2 = r2.data_ptr(), r2.shape[-1], r2_coff, r2_cend, beta2
     if mz is not None:
-        d.mz, d.mz_cs, d.mz_coff, d.mz_c0 = mz.data_ptr(), mz.shape[3], mz_coff, mz_c0
+        d.mz, d.mz_cs, d.mz_coff, d.mz_c0 = mz.data_ptr(), mz.shape[-1], mz_coff, mz_c0
     d.alpha, d.slope, d.mslope, d.act = alpha, slope, mslope, int(act)
+    d.x_plane, d.y_plane, d.r1_plane, d.r2_plane, d.mz_plane = x_plane, y_plane, r1_plane, r2_plane, mz_plane
     N.check(N.lib().srcgan_conv_igemm(C.byref(d), N.stream_ptr(x.device)), "srcgan_conv_igemm")
     return y
 
