@@ -93,7 +93,7 @@ def pmc_traffic(cls):
         return None
     base, mt = m.group(1), re.search(r"MT(\d)", cls)
     for name, v in data.items():           # rocprof demangles template arguments inconsistently: match on kernel + MT
-        if base in name and (mt is None or f", {mt.group(1)}, " in name or f"Li{mt.group(1)}E" in name):
+        if base in name and (mt is None or re.search(rf"<[^,<>]+, {mt.group(1)}[,>]", name) or f"Li{mt.group(1)}E" in name):
             return v["hbm_bytes_per_launch"]
     return None
 

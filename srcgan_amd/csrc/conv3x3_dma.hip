@@ -196,6 +196,190 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Loader-specialised variant: 8 MFMA waves + 4 loader waves in DISJOINT code regions (separate loops with matching
+// barrier counts), so the register allocation is max(loader, compute) instead of their union, and the DMA stream is
+// issued by waves that do nothing else.  Diagnostic that motivated it: issuing the next stage's DMA *after* the
+// MFMAs instead of before them did not change the run time -- the DMA issued by an MFMA wave does not overlap that
+// wave's compute.
+template <typename T, int MT>
+__global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
+    using D = DT<T>;
+    constexpr int NWV = 8, NLW = 4, PT = 2;
+    constexpr int TH = PT * NWV, TW = 32, IHT = TH + 2, IWT = TW + 2;
+    constexpr int COT = 32 * MT, NTAP = 9;
+    constexpr int NHP = IHT * IWT;
+    constexpr int HPIECES = (NHP * 64 + 1023) / 1024, WPIECES = NTAP * COT * 64 / 1024;
+    constexpr int HBYTES = HPIECES * 1024, WBYTES = WPIECES * 1024, SBYTES = HBYTES + WBYTES;
+    constexpr int HIT = (HPIECES + NLW - 1) / NLW, WIT = (WPIECES + NLW - 1) / NLW;
+    constexpr int ERS = COT * 4 + 16;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nunits = p.tiles_x * p.tiles_y * p.B * p.ctiles;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, gw = (gridDim.x + 7 - xcd) >> 3;
+    const int u8 = (nunits + 7) >> 3;
+    const int u_lo = xcd * u8, u_hi = (u_lo + u8 < nunits) ? u_lo + u8 : nunits;
+    const int u0 = u_lo + jw;
+    if (u0 >= u_hi) return;
+
+    if (wave >= NWV) {
+        // ================================================================== loader waves
+        const int iw = wave - NWV;
+        const char* zp = (const char*)sg_zero_page;
+        int h_goff[HIT];
+        const char* f_xb = nullptr; const char* f_wb = nullptr;
+        auto setup_fetch = [&](int u) {
+            const int ct = u % p.ctiles; int t = u / p.ctiles;
+            const int tx = t % p.tiles_x; t /= p.tiles_x;
+            const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+            const int gy0 = ty * TH - p.pad_y, gx0 = tx * TW - p.pad_x;
+            f_xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix;
+            f_wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int q = (it * NLW + iw) * 64 + lane, lp = q >> 2;
+                const int iy = lp / IWT, ix = lp - iy * IWT;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                const bool ok = lp < NHP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                h_goff[it] = ok ? (gy * p.W + gx) * (int)p.xpix : -1;
+            }
+        };
+        auto issue = [&](int c, int stage) {
+            char* lh = smem + stage * SBYTES;
+            char* lw = lh + HBYTES;
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int pi = it * NLW + iw;
+                if (HIT * NLW == HPIECES || pi < HPIECES) {
+                    const int q = pi * 64 + lane, lp = q >> 2;
+                    const int chl = c * D::KCE + ((q & 3) ^ ((lp >> 2) & 3)) * D::EPP;
+                    const bool ok = h_goff[it] >= 0 && chl < p.Cin;
+                    const char* src = ok ? f_xb + h_goff[it] + chan_off<T>(p.xcoff + chl, p.xplane) : zp;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lh + pi * 1024), 16, 0, 0);
+                }
+            }
+            const char* ws = f_wb + (size_t)c * NTAP * COT * 64;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pi = it * NLW + iw;
+                if (WIT * NLW == WPIECES || pi < WPIECES) {
+                    const int q = pi * 64 + lane, wr = q >> 2;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ws + wr * 64 + (((q & 3) ^ ((wr >> 2) & 3)) * 16)), (lptr_t)(lw + pi * 1024), 16, 0, 0);
+                }
+            }
+        };
+        setup_fetch(u0);
+        issue(0, 0);
+        int stage = 0;
+        for (int u = u0; u < u_hi; u += gw) {
+            for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
+                __syncthreads();                 // my pieces of this stage landed (vmcnt 0); MFMA waves left the other stage
+                if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
+                else if (u + gw < u_hi) { setup_fetch(u + gw); issue(0, stage ^ 1); }
+            }
+            if (p.vec16) __syncthreads();        // matches the MFMA waves' pre-epilogue barrier
+        }
+        return;
+    }
+
+    // ====================================================================== MFMA waves
+    const int r = lane & 31, h = lane >> 5;
+    const int wsw = (r >> 2) & 3;
+    int stage = 0;
+    for (int u = u0; u < u_hi; u += gw) {
+        const int cct = u % p.ctiles; int t = u / p.ctiles;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; const int cb = t / p.tiles_y;
+        const int coy0 = ty * TH, cox0 = tx * TW;
+        f32x16 acc[MT][PT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+        for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
+            __syncthreads();
+            const char* lh = smem + stage * SBYTES;
+            const char* lw = lh + HBYTES;
+            using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
+            frag_t fa[2][MT], fb[2][PT];
+            auto load_step = [&](int s, frag_t (&a)[MT], frag_t (&bq)[PT]) {
+                const int tap = s >> 1, ks = s & 1, ky = tap / 3, kx = tap - ky * 3;
+                const int kp = ks * 2 + h;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *(const frag_t*)(lw + (tap * COT + m * 32 + r) * 64 + ((kp ^ wsw) * 16));
+#pragma unroll
+                for (int q = 0; q < PT; ++q) {
+                    const int lp = (wave * PT + q + ky) * IWT + r + kx;
+                    bq[q] = *(const frag_t*)(lh + lp * 64 + ((kp ^ ((lp >> 2) & 3)) * 16));
+                }
+            };
+            load_step(0, fa[0], fb[0]);
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int q = 0; q < PT; ++q)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][m][j], fb[s & 1][q][j], acc[m][q], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < PT; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][m], fb[s & 1][q], acc[m][q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.vec16) {
+            __syncthreads();
+            char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+                conv_epilogue_lds_row<T, MT, PT>(p, acc, q, tsp, cb, cct, coy0 + wave * PT + q, cox0, lane);
+        } else {
+            conv_epilogue<T, MT, PT>(p, acc, cb, cct, coy0 + wave * PT, cox0, r, h);
+        }
+    }
+}
+
+template <typename T, int MT>
+static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
+    constexpr int HB = ((18 * 34 * 64 + 1023) / 1024) * 1024, WB = 9 * 32 * MT * 64;
+    constexpr size_t SMEM = 2 * ((size_t)HB + (size_t)WB);
+    auto kern = conv3x3_ls_k<T, MT>;
+    static bool attr_set = false;
+    static int ncu = 0;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        int dev = 0; hipDeviceProp_t prop;
+        SG_HIP(hipGetDevice(&dev)); SG_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    ConvP q = p;
+    q.tiles_x = cdiv(p.OW, 32); q.tiles_y = cdiv(p.OH, 16); q.ctiles = ctiles;
+    const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
+    size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
+    char cls[96];
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT);
+    const double px = (double)p.B * p.OH * p.OW;
+    const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), SMEM, st, q);
+    sg_prof_stop(tok, st);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T, int MT, int NWV, int NBUF, int PT, int NLW = 0>
 static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int TH = PT * NWV;
@@ -238,18 +422,14 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
 template <typename T>
 static int dispatch_dma(const ConvP& p, hipStream_t st) {
     static const char* cfg_env = getenv("SRCGAN_DMA_CFG");
-    const char cfg = cfg_env ? cfg_env[0] : 'a';
+    const char cfg = cfg_env ? cfg_env[0] : 'l';     // 'l': 8 MFMA + 4 loader waves (default); 'a': 8 self-loading waves
     if (p.Cout <= 32) {
-        if (cfg == 'b') return launch_dma<T, 1, 4, 2, 2>(p, 1, st);
-        if (cfg == 'd') return launch_dma<T, 1, 4, 2, 4>(p, 1, st);
-        if (cfg == 'l') return launch_dma<T, 1, 8, 2, 2, 4>(p, 1, st);
-        return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
+        if (cfg == 'a') return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
+        return launch_ls<T, 1>(p, 1, st);
     }
     const int ctiles = cdiv(p.Cout, 64);
-    if (cfg == 'b') return launch_dma<T, 2, 4, 2, 2>(p, ctiles, st);
-    if (cfg == 'd') return launch_dma<T, 2, 4, 2, 4>(p, ctiles, st);
-    if (cfg == 'l') return launch_dma<T, 2, 8, 2, 2, 4>(p, ctiles, st);
-    return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
+    if (cfg == 'a') return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
+    return launch_ls<T, 2>(p, ctiles, st);
 }
 
 // entry used by srcgan_conv_igemm for kh == kw == 3, stride 1
