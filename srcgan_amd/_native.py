@@ -12,7 +12,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrcgan_amd.so")
+# SRCGAN_AMD_LIB: developer override used by the kernel-variant experiments in scripts/ (A/B builds side by side)
+LIB_PATH = os.environ.get("SRCGAN_AMD_LIB") or os.path.join(_HERE, "lib", "libsrcgan_amd.so")
 
 F32, BF16 = 0, 1
 _DTYPES = {"fp32": F32, "f32": F32, "float32": F32, torch.float32: F32,

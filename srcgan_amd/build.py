@@ -48,6 +48,8 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    import ctypes
+    ctypes.CDLL(LIB)          # a kernel whose host stub was not emitted links fine but fails here (undefined symbol)
     return LIB
 
 

@@ -202,6 +202,13 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
 // issued by waves that do nothing else.  Diagnostic that motivated it: issuing the next stage's DMA *after* the
 // MFMAs instead of before them did not change the run time -- the DMA issued by an MFMA wave does not overlap that
 // wave's compute.
+// 16 B per lane, global -> LDS, through a raw buffer descriptor {base, num_records = nrec bytes}: lanes whose byte
+// offset is outside [0, nrec) write zeros (hardware range check).  `base`/`nrec`/`lds` must be wave-uniform.
+__device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, lptr_t lds) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, 0, 0, 0);
+}
+
 template <typename T, int MT>
 __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
@@ -210,8 +217,10 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
     constexpr int COT = 32 * MT, NTAP = 9;
     constexpr int NHP = IHT * IWT;
     constexpr int HPIECES = (NHP * 64 + 1023) / 1024, WPIECES = NTAP * COT * 64 / 1024;
-    constexpr int HBYTES = HPIECES * 1024, WBYTES = WPIECES * 1024, SBYTES = HBYTES + WBYTES;
     constexpr int HIT = (HPIECES + NLW - 1) / NLW, WIT = (WPIECES + NLW - 1) / NLW;
+    // every loader wave issues HIT + WIT DMAs per chunk with no per-piece branch: the LDS regions are rounded up to
+    // whole rounds of NLW pieces and the surplus pieces carry out-of-range offsets (zero fill, no memory traffic)
+    constexpr int HBYTES = HIT * NLW * 1024, WBYTES = WIT * NLW * 1024, SBYTES = HBYTES + WBYTES;
     constexpr int ERS = COT * 4 + 16;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,58 +234,92 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
 
     if (wave >= NWV) {
         // ================================================================== loader waves
+        // Steady state = scalar ALU + DMA only.  Measured (scripts/hip/overlap_test.hip): beside two MFMA waves per
+        // SIMD a loader wave that needs VALU for its addresses is starved to 1/16 of its stream rate, whatever its
+        // s_setprio; a loader issuing `buffer_load_dwordx4 voff, rsrc, 0 offen lds` from precomputed per-lane offsets
+        // keeps the full 6.4 TB/s.  So:
+        //  * per-lane byte offsets relative to the tile origin are computed ONCE, for the 3x3 tile classes
+        //    {first, interior, last} row x column of tiles; lanes outside the image (or past Cin) hold an offset beyond
+        //    num_records and the buffer range check zero-fills them;
+        //  * the tile origin, the K-chunk advance and the unit decode (ct, tx, ty, b advance by a fixed step with
+        //    carries) are scalar.
         const int iw = wave - NWV;
-        const char* zp = (const char*)sg_zero_page;
-        int h_goff[HIT];
-        const char* f_xb = nullptr; const char* f_wb = nullptr;
-        auto setup_fetch = [&](int u) {
-            const int ct = u % p.ctiles; int t = u / p.ctiles;
-            const int tx = t % p.tiles_x; t /= p.tiles_x;
-            const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+        constexpr int OOB = 0x7fffffff;
+        const long cstride = p.xplane ? p.xplane : 64;                   // bytes between consecutive K chunks
+        const int nrec = (IHT * p.W + IWT) * (int)p.xpix;                 // bound on a halo tile's offsets from its origin
+        const int tail = p.Cin - (p.nchunk - 1) * D::KCE;                 // channels in the last chunk
+        int wv[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int pi = it * NLW + iw, q = pi * 64 + lane, wr = q >> 2;
+            wv[it] = pi < WPIECES ? wr * 64 + (((q & 3) ^ ((wr >> 2) & 3)) * 16) : OOB;
+        }
+        // nine separately named tables (an array of tables gets indexed dynamically by the tile class -> scratch)
+        int tab0[HIT], tab1[HIT], tab2[HIT], tab3[HIT], tab4[HIT], tab5[HIT], tab6[HIT], tab7[HIT], tab8[HIT];
+        auto fill = [&](int (&tab)[HIT], int cy, int cx) __attribute__((always_inline)) {
+            const int ty = cy == 0 ? 0 : cy == 2 ? p.tiles_y - 1 : 1, tx = cx == 0 ? 0 : cx == 2 ? p.tiles_x - 1 : 1;
             const int gy0 = ty * TH - p.pad_y, gx0 = tx * TW - p.pad_x;
-            f_xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix;
-            f_wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
 #pragma unroll
             for (int it = 0; it < HIT; ++it) {
                 const int q = (it * NLW + iw) * 64 + lane, lp = q >> 2;
                 const int iy = lp / IWT, ix = lp - iy * IWT;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                const bool ok = lp < NHP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                h_goff[it] = ok ? (gy * p.W + gx) * (int)p.xpix : -1;
+                const int sw = (q & 3) ^ ((lp >> 2) & 3);
+                const bool ok = lp < NHP && (unsigned)(gy0 + iy) < (unsigned)p.H && (unsigned)(gx0 + ix) < (unsigned)p.W && sw * D::EPP < tail;
+                tab[it] = ok ? (iy * p.W + ix) * (int)p.xpix + sw * 16 : OOB;
             }
         };
-        auto issue = [&](int c, int stage) {
+        fill(tab0, 0, 0); fill(tab1, 0, 1); fill(tab2, 0, 2); fill(tab3, 1, 0); fill(tab4, 1, 1);
+        fill(tab5, 1, 2); fill(tab6, 2, 0); fill(tab7, 2, 1); fill(tab8, 2, 2);
+        // unit decode, advanced by gw units at a time with scalar carries
+        int uct = u0 % p.ctiles, utx, uty, ub;
+        { int t = u0 / p.ctiles; utx = t % p.tiles_x; t /= p.tiles_x; uty = t % p.tiles_y; ub = t / p.tiles_y; }
+        int dct = gw % p.ctiles, dtx, dty, db;
+        { int t = gw / p.ctiles; dtx = t % p.tiles_x; t /= p.tiles_x; dty = t % p.tiles_y; db = t / p.tiles_y; }
+        uct = __builtin_amdgcn_readfirstlane(uct); utx = __builtin_amdgcn_readfirstlane(utx);
+        uty = __builtin_amdgcn_readfirstlane(uty); ub = __builtin_amdgcn_readfirstlane(ub);
+        dct = __builtin_amdgcn_readfirstlane(dct); dtx = __builtin_amdgcn_readfirstlane(dtx);
+        dty = __builtin_amdgcn_readfirstlane(dty); db = __builtin_amdgcn_readfirstlane(db);
+        auto advance = [&]() {
+            uct += dct; if (uct >= p.ctiles) { uct -= p.ctiles; ++utx; }
+            utx += dtx; if (utx >= p.tiles_x) { utx -= p.tiles_x; ++uty; }
+            uty += dty; if (uty >= p.tiles_y) { uty -= p.tiles_y; ++ub; }
+            ub += db;
+        };
+        const char* xb0 = (const char*)p.x + chan_off<T>(p.xcoff, p.xplane);
+        auto issue = [&](int c, int stage) __attribute__((always_inline)) {             // chunk c of the unit (uct, utx, uty, ub)
             char* lh = smem + stage * SBYTES;
             char* lw = lh + HBYTES;
-#pragma unroll
-            for (int it = 0; it < HIT; ++it) {
-                const int pi = it * NLW + iw;
-                if (HIT * NLW == HPIECES || pi < HPIECES) {
-                    const int q = pi * 64 + lane, lp = q >> 2;
-                    const int chl = c * D::KCE + ((q & 3) ^ ((lp >> 2) & 3)) * D::EPP;
-                    const bool ok = h_goff[it] >= 0 && chl < p.Cin;
-                    const char* src = ok ? f_xb + h_goff[it] + chan_off<T>(p.xcoff + chl, p.xplane) : zp;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lh + pi * 1024), 16, 0, 0);
-                }
+            const long org = ((long)ub * p.H + (uty * TH - p.pad_y)) * p.W + (utx * TW - p.pad_x);     // tile origin, pixels
+            const char* bx = xb0 + org * p.xpix + c * cstride;
+            const char* bw = (const char*)p.wp + ((size_t)uct * p.nchunk + c) * NTAP * COT * 64;
+            const int cls = (uty == 0 ? 0 : uty == p.tiles_y - 1 ? 2 : 1) * 3 + (utx == 0 ? 0 : utx == p.tiles_x - 1 ? 2 : 1);
+#ifndef SG_HACK_NOHALO
+#define SG_ISSUE_CLASS(K)                                                                             \
+            case K:                                                                                   \
+                _Pragma("unroll") for (int it = 0; it < HIT; ++it)                                     \
+                    dma_buf16(bx, nrec, tab##K[it], (lptr_t)(lh + (it * NLW + iw) * 1024));            \
+                asm volatile("; tile class " #K);   /* a distinct tail: cases merged by code sinking index the tables in scratch */ \
+                break;
+            switch (cls) {
+                SG_ISSUE_CLASS(0) SG_ISSUE_CLASS(1) SG_ISSUE_CLASS(2) SG_ISSUE_CLASS(3) SG_ISSUE_CLASS(4)
+                SG_ISSUE_CLASS(5) SG_ISSUE_CLASS(6) SG_ISSUE_CLASS(7) SG_ISSUE_CLASS(8)
             }
-            const char* ws = f_wb + (size_t)c * NTAP * COT * 64;
+#undef SG_ISSUE_CLASS
+#endif
+#ifndef SG_HACK_NOW
 #pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int pi = it * NLW + iw;
-                if (WIT * NLW == WPIECES || pi < WPIECES) {
-                    const int q = pi * 64 + lane, wr = q >> 2;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ws + wr * 64 + (((q & 3) ^ ((wr >> 2) & 3)) * 16)), (lptr_t)(lw + pi * 1024), 16, 0, 0);
-                }
-            }
+            for (int it = 0; it < WIT; ++it)
+                dma_buf16(bw, NTAP * COT * 64, wv[it], (lptr_t)(lw + (it * NLW + iw) * 1024));
+#endif
         };
-        setup_fetch(u0);
         issue(0, 0);
         int stage = 0;
         for (int u = u0; u < u_hi; u += gw) {
             for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
                 __syncthreads();                 // my pieces of this stage landed (vmcnt 0); MFMA waves left the other stage
+                if (p.dbg & 2) continue;
                 if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
-                else if (u + gw < u_hi) { setup_fetch(u + gw); issue(0, stage ^ 1); }
+                else if (u + gw < u_hi) { advance(); issue(0, stage ^ 1); }
             }
             if (p.vec16) __syncthreads();        // matches the MFMA waves' pre-epilogue barrier
         }
@@ -284,8 +327,31 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
     }
 
     // ====================================================================== MFMA waves
+    // Row-ordered schedule.  A wave owns PT output rows x 32 pixels x COT channels.  Per K chunk and k-half `ks` it walks
+    // the PT+2 input rows i and the 3 horizontal taps kx: ONE pixel fragment B(i,kx) feeds every (output row q, ky)
+    // pair with q + ky == i, so the pixel operand is read (PT+2)*3 times per k-half instead of PT*9 -- the LDS read
+    // stream, not the matrix pipe, bounds this loop (measured: dropping 1 of 6 reads speeds it up by the same 1/6).
+    // Weight fragments A(ky,kx) live in a 6-slot register ring (each is used by two groups three apart).
+    // LDS->register prefetch runs PD groups ahead, across k-halves, and is drained only at the chunk barrier.
     const int r = lane & 31, h = lane >> 5;
-    const int wsw = (r >> 2) & 3;
+    using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
+#ifndef SG_PD
+#define SG_PD 2
+#endif
+    constexpr int PD = SG_PD, NRB = PD + 1, NRA = 6;
+    constexpr int NGRP = (PT + 2) * 3, NG2 = 2 * NGRP;               // groups per k-half / per chunk
+    static_assert(PT == 2 && PD >= 1 && PD <= 2, "A-ring size assumes PT == 2 and PD <= 2");
+    // byte offsets inside a stage (stage 0), k-half 0; k-half 1 is the same address with bit 5 flipped (slot ^ 2)
+    int pb[NGRP], pa;
+    {
+        const int L0 = wave * PT * IWT + r;
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            const int lp = L0 + (g / 3) * IWT + (g % 3);
+            pb[g] = lp * 64 + ((h ^ ((lp >> 2) & 3)) * 16);
+        }
+        pa = HBYTES + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);
+    }
     int stage = 0;
     for (int u = u0; u < u_hi; u += gw) {
         const int cct = u % p.ctiles; int t = u / p.ctiles;
@@ -301,41 +367,44 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
                 for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
         for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
             __syncthreads();
-            const char* lh = smem + stage * SBYTES;
-            const char* lw = lh + HBYTES;
-            using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
-            frag_t fa[2][MT], fb[2][PT];
-            auto load_step = [&](int s, frag_t (&a)[MT], frag_t (&bq)[PT]) {
-                const int tap = s >> 1, ks = s & 1, ky = tap / 3, kx = tap - ky * 3;
-                const int kp = ks * 2 + h;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    a[m] = *(const frag_t*)(lw + (tap * COT + m * 32 + r) * 64 + ((kp ^ wsw) * 16));
-#pragma unroll
-                for (int q = 0; q < PT; ++q) {
-                    const int lp = (wave * PT + q + ky) * IWT + r + kx;
-                    bq[q] = *(const frag_t*)(lh + lp * 64 + ((kp ^ ((lp >> 2) & 3)) * 16));
-                }
+            if (p.dbg & 1) continue;
+            const char* ls = smem + stage * SBYTES;
+            frag_t fa[NRA][MT], fb[NRB];
+            // flat group index G = ks * NGRP + i * 3 + kx
+            auto read_b = [&](int G) {
+                const int ks = G / NGRP, g = G % NGRP;
+                fb[G % NRB] = *(const frag_t*)(ls + (pb[g] ^ (ks * 32)));
             };
-            load_step(0, fa[0], fb[0]);
-#pragma unroll
-            for (int s = 0; s < 18; ++s) {
-                if (s + 1 < 18) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int q = 0; q < PT; ++q)
-                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][m][j], fb[s & 1][q][j], acc[m][q], 0, 0, 0);
-                } else {
+            auto read_a = [&](int G) {                   // the weight tap first used by group G (none for the last input row)
+                const int ks = G / NGRP, g = G % NGRP;
+                if (g < 9) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
+                        fa[g % NRA][m] = *(const frag_t*)(ls + (pa ^ (ks * 32)) + (g * COT + m * 32) * 64);
+                }
+            };
 #pragma unroll
-                        for (int q = 0; q < PT; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][m], fb[s & 1][q], acc[m][q], 0, 0, 0);
+            for (int G = 0; G < PD; ++G) { read_a(G); read_b(G); }
+#pragma unroll
+            for (int G = 0; G < NG2; ++G) {
+                if (G + PD < NG2) { read_a(G + PD); read_b(G + PD); }
+                __builtin_amdgcn_sched_barrier(0);
+                const int g = G % NGRP, i = g / 3, kx = g % 3;
+#pragma unroll
+                for (int q = 0; q < PT; ++q) {
+                    const int ky = i - q;
+                    if (ky < 0 || ky > 2) continue;
+                    const int ta = (ky * 3 + kx) % NRA;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ta][m][jj], fb[G % NRB][jj], acc[m][q], 0, 0, 0);
+                        } else {
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta][m], fb[G % NRB], acc[m][q], 0, 0, 0);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -343,6 +412,7 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
         if (p.vec16) {
             __syncthreads();
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
+            if (!(p.dbg & 4))
 #pragma unroll
             for (int q = 0; q < PT; ++q)
                 conv_epilogue_lds_row<T, MT, PT>(p, acc, q, tsp, cb, cct, coy0 + wave * PT + q, cox0, lane);
@@ -354,7 +424,7 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
 
 template <typename T, int MT>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
-    constexpr int HB = ((18 * 34 * 64 + 1023) / 1024) * 1024, WB = 9 * 32 * MT * 64;
+    constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + 3) / 4) * 4096, WB = ((9 * 32 * MT * 64 / 1024 + 3) / 4) * 4096;
     constexpr size_t SMEM = 2 * ((size_t)HB + (size_t)WB);
     auto kern = conv3x3_ls_k<T, MT>;
     static bool attr_set = false;
@@ -368,6 +438,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     }
     ConvP q = p;
     q.tiles_x = cdiv(p.OW, 32); q.tiles_y = cdiv(p.OH, 16); q.ctiles = ctiles;
+    { static const char* e = getenv("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
@@ -422,7 +493,11 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
 template <typename T>
 static int dispatch_dma(const ConvP& p, hipStream_t st) {
     static const char* cfg_env = getenv("SRCGAN_DMA_CFG");
-    const char cfg = cfg_env ? cfg_env[0] : 'l';     // 'l': 8 MFMA + 4 loader waves (default); 'a': 8 self-loading waves
+    char cfg = cfg_env ? cfg_env[0] : 'l';     // 'l': 8 MFMA + 4 loader waves (default); 'a': 8 self-loading waves
+    // the loader-specialised kernel needs a uniform K-chunk stride and 31-bit per-image offsets
+    const bool ls_ok = (p.xplane == 0 || p.xcoff % DT<T>::KCE == 0) && (p.Cin % DT<T>::KCE == 0 || p.nchunk == 1) &&
+                       p.pad_y == 1 && p.pad_x == 1 && (18.0 * p.W + 34.0) * (double)p.xpix < 2147483647.0;
+    if (!ls_ok) cfg = 'a';
     if (p.Cout <= 32) {
         if (cfg == 'a') return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
         return launch_ls<T, 1>(p, 1, st);
