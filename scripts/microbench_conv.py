@@ -20,7 +20,10 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 if which in ("all", "igemm"):
-    for cin, cout in [(64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64), (32, 64)]:
+    shapes = [(64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64), (32, 64)]
+    if os.environ.get("MB_SHAPES"):                  # e.g. MB_SHAPES="192:64,64:32"
+        shapes = [tuple(int(v) for v in t.split(":")) for t in os.environ["MB_SHAPES"].split(",")]
+    for cin, cout in shapes:
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         wp = ops.pack_conv2d_fwd(w, dt)
         b = torch.zeros(cout, device="cuda")

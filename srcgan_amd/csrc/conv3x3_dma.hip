@@ -202,6 +202,14 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
 // issued by waves that do nothing else.  Diagnostic that motivated it: issuing the next stage's DMA *after* the
 // MFMAs instead of before them did not change the run time -- the DMA issued by an MFMA wave does not overlap that
 // wave's compute.
+// Workgroup barriers of the loader-specialised kernel.  __syncthreads() waits for vmcnt(0) AND lgkmcnt(0) in every wave:
+// for an MFMA wave that is the acknowledgement of its epilogue's global stores (~2 us, once per unit, traced), for a
+// loader wave at the pre-epilogue barrier it is the landing of the NEXT unit's first stage.  Each role waits only for
+// what the LDS hand-over needs: MFMA waves for their own LDS reads/writes, loader waves for their own DMA.
+__device__ __forceinline__ void sg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void sg_barrier_dma() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void sg_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
+
 // 16 B per lane, global -> LDS, through a raw buffer descriptor {base, num_records = nrec bytes}: lanes whose byte
 // offset is outside [0, nrec) write zeros (hardware range check).  `base`/`nrec`/`lds` must be wave-uniform.
 __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, lptr_t lds) {
@@ -209,10 +217,10 @@ __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, 0, 0, 0);
 }
 
-template <typename T, int MT>
-__global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
+template <typename T, int MT, int NLW>
+__global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
-    constexpr int NWV = 8, NLW = 4, PT = 2;
+    constexpr int NWV = 8, PT = 2;
     constexpr int TH = PT * NWV, TW = 32, IHT = TH + 2, IWT = TW + 2;
     constexpr int COT = 32 * MT, NTAP = 9;
     constexpr int NHP = IHT * IWT;
@@ -231,6 +239,9 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
     const int u_lo = xcd * u8, u_hi = (u_lo + u8 < nunits) ? u_lo + u8 : nunits;
     const int u0 = u_lo + jw;
     if (u0 >= u_hi) return;
+    // bias (zero-padded to ctiles * COT) staged behind the two stages; first read after >= 1 workgroup barrier
+    for (int i = tid; i < p.ctiles * COT; i += (NWV + NLW) * 64)
+        ((float*)(smem + 2 * SBYTES))[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
 
     if (wave >= NWV) {
         // ================================================================== loader waves
@@ -313,15 +324,29 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
 #endif
         };
         issue(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the LDS bias copy
         int stage = 0;
+        int trk = 0;
         for (int u = u0; u < u_hi; u += gw) {
             for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
-                __syncthreads();                 // my pieces of this stage landed (vmcnt 0); MFMA waves left the other stage
+#ifdef SG_TRACE
+                __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): my DMA pieces landed
+                const unsigned long long t_land = __builtin_amdgcn_s_memrealtime();
+#endif
+                sg_barrier_dma();                // my pieces of this stage landed (vmcnt 0); MFMA waves left the other stage
+#ifdef SG_TRACE
+                const unsigned long long t_bar = __builtin_amdgcn_s_memrealtime();
+#endif
                 if (p.dbg & 2) continue;
                 if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
                 else if (u + gw < u_hi) { advance(); issue(0, stage ^ 1); }
+#ifdef SG_TRACE
+                if (p.trace && blockIdx.x == 8 && iw == 0 && lane == 0 && trk < 60) {
+                    p.trace[trk * 8 + 0] = t_land; p.trace[trk * 8 + 1] = t_bar; p.trace[trk * 8 + 2] = __builtin_amdgcn_s_memrealtime(); ++trk;
+                }
+#endif
             }
-            if (p.vec16) __syncthreads();        // matches the MFMA waves' pre-epilogue barrier
+            if (p.vec16) sg_barrier_raw();       // matches the MFMA waves' pre-epilogue barrier; the next stage keeps flying
         }
         return;
     }
@@ -353,6 +378,7 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
         pa = HBYTES + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);
     }
     int stage = 0;
+    int trk = 0;
     for (int u = u0; u < u_hi; u += gw) {
         const int cct = u % p.ctiles; int t = u / p.ctiles;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -366,7 +392,15 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
         for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
-            __syncthreads();
+#ifdef SG_TRACE
+            const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
+#endif
+            sg_barrier_lds();
+#ifdef SG_TRACE
+            if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk < 60) {
+                p.trace[trk * 8 + 4] = t_arr; p.trace[trk * 8 + 5] = __builtin_amdgcn_s_memrealtime(); ++trk;
+            }
+#endif
             if (p.dbg & 1) continue;
             const char* ls = smem + stage * SBYTES;
             frag_t fa[NRA][MT], fb[NRB];
@@ -410,23 +444,32 @@ __global__ __launch_bounds__(768) void conv3x3_ls_k(const ConvP p) {
             }
         }
         if (p.vec16) {
-            __syncthreads();
+#ifdef SG_TRACE
+            const unsigned long long t_pre = __builtin_amdgcn_s_memrealtime();
+#endif
+            sg_barrier_lds();
+#ifdef SG_TRACE
+            const unsigned long long t_eb = __builtin_amdgcn_s_memrealtime();
+#endif
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
             if (!(p.dbg & 4))
-#pragma unroll
-            for (int q = 0; q < PT; ++q)
-                conv_epilogue_lds_row<T, MT, PT>(p, acc, q, tsp, cb, cct, coy0 + wave * PT + q, cox0, lane);
+                conv_epilogue_lds_rows<T, MT, PT>(p, acc, tsp, smem + 2 * SBYTES, cb, cct, coy0 + wave * PT, cox0, lane);
+#ifdef SG_TRACE
+            if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk <= 60) {
+                p.trace[(trk - 1) * 8 + 3] = t_pre; p.trace[(trk - 1) * 8 + 6] = t_eb; p.trace[(trk - 1) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+            }
+#endif
         } else {
             conv_epilogue<T, MT, PT>(p, acc, cb, cct, coy0 + wave * PT, cox0, r, h);
         }
     }
 }
 
-template <typename T, int MT>
+template <typename T, int MT, int NLW>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
-    constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + 3) / 4) * 4096, WB = ((9 * 32 * MT * 64 / 1024 + 3) / 4) * 4096;
-    constexpr size_t SMEM = 2 * ((size_t)HB + (size_t)WB);
-    auto kern = conv3x3_ls_k<T, MT>;
+    constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
+    constexpr size_t SMEM = 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
+    auto kern = conv3x3_ls_k<T, MT, NLW>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -442,10 +485,38 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), SMEM, st, q);
+#ifdef SG_TRACE
+    static unsigned long long* trace = nullptr;
+    if (!trace) { SG_HIP(hipMalloc(&trace, 60 * 8 * 8)); }
+    SG_HIP(hipMemsetAsync(trace, 0, 60 * 8 * 8, st));
+    q.trace = trace;
+#else
+    q.trace = nullptr;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((8 + NLW) * 64), SMEM, st, q);
+#ifdef SG_TRACE
+    {
+        static int dumps = 0;
+        if (getenv("SRCGAN_TRACE") && dumps < 3) {
+            ++dumps;
+            unsigned long long h[60 * 8];
+            SG_HIP(hipStreamSynchronize(st));
+            SG_HIP(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[trace] %s Cin=%d Cout=%d nchunk=%d  (10 ns ticks rel. to first barrier: loader land, loader barrier-exit, loader issue-done | mfma arrive, mfma barrier-exit)\n", cls, p.Cin, p.Cout, p.nchunk);
+            const unsigned long long t0 = h[1];
+            for (int k = 0; k < 60 && h[k * 8 + 1]; ++k)
+            {
+                fprintf(stderr, "[trace] %2d  L: land %6lld bar %6lld issued %6lld | M: arrive %6lld bar %6lld", k, (long long)(h[k * 8] - t0), (long long)(h[k * 8 + 1] - t0),
+                        (long long)(h[k * 8 + 2] - t0), (long long)(h[k * 8 + 4] - t0), (long long)(h[k * 8 + 5] - t0));
+                if (h[k * 8 + 3]) fprintf(stderr, " | last-chunk done %6lld epi-barrier %6lld epi-done %6lld", (long long)(h[k * 8 + 3] - t0), (long long)(h[k * 8 + 6] - t0), (long long)(h[k * 8 + 7] - t0));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     sg_prof_stop(tok, st);
     SG_LAUNCH_CHECK();
     return 0;
@@ -496,15 +567,19 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
     char cfg = cfg_env ? cfg_env[0] : 'l';     // 'l': 8 MFMA + 4 loader waves (default); 'a': 8 self-loading waves
     // the loader-specialised kernel needs a uniform K-chunk stride and 31-bit per-image offsets
     const bool ls_ok = (p.xplane == 0 || p.xcoff % DT<T>::KCE == 0) && (p.Cin % DT<T>::KCE == 0 || p.nchunk == 1) &&
-                       p.pad_y == 1 && p.pad_x == 1 && (18.0 * p.W + 34.0) * (double)p.xpix < 2147483647.0;
+                       p.pad_y == 1 && p.pad_x == 1 && p.Cout <= 1024 && (18.0 * p.W + 34.0) * (double)p.xpix < 2147483647.0;
     if (!ls_ok) cfg = 'a';
     if (p.Cout <= 32) {
         if (cfg == 'a') return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
-        return launch_ls<T, 1>(p, 1, st);
+#ifndef SG_NLW1
+#define SG_NLW1 8
+#endif
+        if constexpr (sizeof(T) == 4) return launch_ls<T, 1, 4>(p, 1, st);      // fp32: 128 VGPRs (16 waves) would spill
+        else return launch_ls<T, 1, SG_NLW1>(p, 1, st);
     }
     const int ctiles = cdiv(p.Cout, 64);
     if (cfg == 'a') return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
-    return launch_ls<T, 2>(p, ctiles, st);
+    return launch_ls<T, 2, 4>(p, ctiles, st);
 }
 
 // entry used by srcgan_conv_igemm for kh == kw == 3, stride 1

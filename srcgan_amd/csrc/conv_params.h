@@ -18,6 +18,7 @@ struct ConvP {
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
+    unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
 };
 
 template <typename T>
@@ -228,6 +229,99 @@ template <typename T, int MT, int PT>
 __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
                                                       int oy, int ox0, int lane) {
     conv_epilogue_lds_row_impl<T, MT, PT>(p, acc, q, lds_wave, b, ct, oy, ox0, lane);
+}
+
+// Epilogue of the loader-specialised 3x3 kernel: all PT rows of a wave.  Differences from the per-row form above, each
+// from a timestamp trace of the kernel (the epilogue was 25-30 % of a unit's time, ~2000 instructions per wave):
+//  * every address is split into a wave-uniform 64-bit part (image, row, tile column, pass: scalar ALU) and a per-lane
+//    part (pixel within the pass, channel) that does not depend on the unit -- no per-pass 64-bit vector multiplies;
+//  * the bias comes from a copy staged in LDS at kernel start (a global load per row exposed ~1 us of latency);
+//  * the residual (r1) and activation-mask (mz) operands of ALL passes of a row are requested before the row's
+//    accumulators go through the LDS transposition, so one memory latency is exposed per row, not one per pass.
+// b, ct, oy0, ox0 must be wave-uniform.
+template <typename T, int MT, int PT>
+__device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32x16 (&acc)[MT][PT], char* lds_wave, const char* lds_bias,
+                                                       int b, int ct, int oy0, int ox0, int lane) {
+    constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
+    constexpr int RS = COT * 4 + 16;
+    constexpr bool PF = NP * 4 * 2 <= 32;            // prefetch the operands of a whole row when that costs <= 32 VGPRs
+    constexpr int NPF = PF ? NP : 1;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int r = lane & 31, h = lane >> 5;
+    const int lx = lane / LPP, c0 = (lane % LPP) * EPP, co0 = ct * COT + c0;
+    const bool cok = co0 < p.Cout;
+    float bias[EPP];
+#pragma unroll
+    for (int i = 0; i < EPP; i += 4) {
+        const f32x4 bv = *(const f32x4*)(lds_bias + (co0 + i) * 4);
+        bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3];
+    }
+    const bool use_r1 = p.r1 && co0 < p.r1cend, use_r2 = p.r2 && co0 < p.r2cend, use_mz = p.mz && co0 >= p.mzc0;
+    // per-lane byte offsets (pixel lx of a pass, channel co0): the same for every unit, row and pass
+    const long lstep = (long)lx * p.os;
+    const long ly = lstep * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane);
+    const long l1 = use_r1 ? lstep * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane) : 0;
+    const long l2 = use_r2 ? lstep * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane) : 0;
+    const long lm = use_mz ? lstep * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane) : 0;
+    const int xrem = p.OW - ox0 - lx;                // pass k is in range iff k * PPP < xrem
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int oy = oy0 + q;
+        const bool rok = cok && oy < p.OH;
+        // wave-uniform: first output pixel of the row segment, and the pixel step between passes
+        const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
+        const long pstep = (long)PPP * p.os;
+        vecT r1v[NPF], mzv[NPF];
+        if (PF) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const bool ok = rok && pass * PPP < xrem;
+                const long px = rowpix + pass * pstep;
+                if (use_r1 && ok) r1v[pass % NPF] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
+                if (use_mz && ok) mzv[pass % NPF] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+                *(f32x4*)(lds_wave + r * RS + (m * 32 + 8 * g + 4 * h) * 4) = v;
+            }
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            float v[EPP];
+#pragma unroll
+            for (int i = 0; i < EPP; i += 4) {
+                const f32x4 t = *(const f32x4*)(lds_wave + (pass * PPP + lx) * RS + (c0 + i) * 4);
+                v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+            }
+            if (!rok || pass * PPP >= xrem) continue;
+            const long px = rowpix + pass * pstep;
+            if (!PF) {
+                if (use_r1) r1v[0] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
+                if (use_mz) mzv[0] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
+            }
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
+            if (use_r1) {
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(r1v[pass % NPF][i]); }
+            if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + px * p.r2pix + l2);
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
+            if (p.act) {
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
+            if (use_mz) {
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) v[i] *= (to_f(mzv[pass % NPF][i]) > 0.f ? 1.f : p.mslope); }
+            vecT o;
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
+            *(vecT*)((char*)p.y + px * p.ypix + ly) = o;
+        }
+    }
 }
 
 // Half-row (16 pixels) variant for kernels whose free LDS slot is small: transpose space = 16 * (COT*4+16) bytes per wave.
