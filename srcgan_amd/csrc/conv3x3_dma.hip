@@ -212,12 +212,16 @@ __device__ __forceinline__ void sg_barrier_raw() { asm volatile("s_barrier" ::: 
 
 // 16 B per lane, global -> LDS, through a raw buffer descriptor {base, num_records = nrec bytes}: lanes whose byte
 // offset is outside [0, nrec) write zeros (hardware range check).  `base`/`nrec`/`lds` must be wave-uniform.
-__device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, lptr_t lds) {
+__device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, lptr_t lds, int soff = 0) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0);
 }
 
-template <typename T, int MT, int NLW>
+// WRES: the packed weights of ALL K chunks stay resident in LDS (one DMA per workgroup at kernel start) and a stage
+// holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
+// 2.6 us per chunk against 1.2 us of MFMA), and the weights are 18 of the 57 KiB a stage moves.  Needs ctiles == 1 and
+// nchunk * 18 KiB + two halo stages within 160 KiB (Cin <= 128 in bf16).
+template <typename T, int MT, int NLW, bool WRES>
 __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
     constexpr int NWV = 8, PT = 2;
@@ -228,7 +232,10 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     constexpr int HIT = (HPIECES + NLW - 1) / NLW, WIT = (WPIECES + NLW - 1) / NLW;
     // every loader wave issues HIT + WIT DMAs per chunk with no per-piece branch: the LDS regions are rounded up to
     // whole rounds of NLW pieces and the surplus pieces carry out-of-range offsets (zero fill, no memory traffic)
-    constexpr int HBYTES = HIT * NLW * 1024, WBYTES = WIT * NLW * 1024, SBYTES = HBYTES + WBYTES;
+    constexpr int HBYTES = HIT * NLW * 1024, WBYTES = WRES ? 0 : WIT * NLW * 1024, SBYTES = HBYTES + WBYTES;
+    constexpr int WCH = NTAP * COT * 64;                         // packed weight bytes per K chunk
+    const int wres_bytes = WRES ? p.nchunk * WCH : 0;            // resident weights sit behind the two stages
+    const int bias_off = 2 * SBYTES + wres_bytes;
     constexpr int ERS = COT * 4 + 16;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     if (u0 >= u_hi) return;
     // bias (zero-padded to ctiles * COT) staged behind the two stages; first read after >= 1 workgroup barrier
     for (int i = tid; i < p.ctiles * COT; i += (NWV + NLW) * 64)
-        ((float*)(smem + 2 * SBYTES))[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
+        ((float*)(smem + bias_off))[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
 
     if (wave >= NWV) {
         // ================================================================== loader waves
@@ -318,11 +325,19 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #undef SG_ISSUE_CLASS
 #endif
 #ifndef SG_HACK_NOW
+            if constexpr (!WRES) {
 #pragma unroll
-            for (int it = 0; it < WIT; ++it)
-                dma_buf16(bw, NTAP * COT * 64, wv[it], (lptr_t)(lw + (it * NLW + iw) * 1024));
+                for (int it = 0; it < WIT; ++it)
+                    dma_buf16(bw, NTAP * COT * 64, wv[it], (lptr_t)(lw + (it * NLW + iw) * 1024));
+            }
 #endif
         };
+        if constexpr (WRES) {
+            // all chunks' weights, once: piece j = 1 KiB = 16 packed rows; lane offset is piece-independent (16 | rows per piece)
+            const int lo = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+            for (int j = iw; j < p.nchunk * (WCH / 1024); j += NLW)
+                dma_buf16(p.wp, wres_bytes, lo, (lptr_t)(smem + 2 * SBYTES + j * 1024), j * 1024);
+        }
         issue(0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the LDS bias copy
         int stage = 0;
@@ -375,7 +390,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
             const int lp = L0 + (g / 3) * IWT + (g % 3);
             pb[g] = lp * 64 + ((h ^ ((lp >> 2) & 3)) * 16);
         }
-        pa = HBYTES + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);
+        pa = (WRES ? 2 * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
     }
     int stage = 0;
     int trk = 0;
@@ -403,6 +418,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #endif
             if (p.dbg & 1) continue;
             const char* ls = smem + stage * SBYTES;
+            const char* lsw = WRES ? smem + c * WCH : ls;
             frag_t fa[NRA][MT], fb[NRB];
             // flat group index G = ks * NGRP + i * 3 + kx
             auto read_b = [&](int G) {
@@ -414,7 +430,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
                 if (g < 9) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        fa[g % NRA][m] = *(const frag_t*)(ls + (pa ^ (ks * 32)) + (g * COT + m * 32) * 64);
+                        fa[g % NRA][m] = *(const frag_t*)(lsw + (pa ^ (ks * 32)) + (g * COT + m * 32) * 64);
                 }
             };
 #pragma unroll
@@ -453,7 +469,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #endif
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
             if (!(p.dbg & 4))
-                conv_epilogue_lds_rows<T, MT, PT>(p, acc, tsp, smem + 2 * SBYTES, cb, cct, coy0 + wave * PT, cox0, lane);
+                conv_epilogue_lds_rows<T, MT, PT>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
 #ifdef SG_TRACE
             if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk <= 60) {
                 p.trace[(trk - 1) * 8 + 3] = t_pre; p.trace[(trk - 1) * 8 + 6] = t_eb; p.trace[(trk - 1) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -465,11 +481,11 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     }
 }
 
-template <typename T, int MT, int NLW>
+template <typename T, int MT, int NLW, bool WRES = false>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
-    constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
-    constexpr size_t SMEM = 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
-    auto kern = conv3x3_ls_k<T, MT, NLW>;
+    constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
+    constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
+    auto kern = conv3x3_ls_k<T, MT, NLW, WRES>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -485,7 +501,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "");
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -575,7 +591,12 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
 #define SG_NLW1 8
 #endif
         if constexpr (sizeof(T) == 4) return launch_ls<T, 1, 4>(p, 1, st);      // fp32: 128 VGPRs (16 waves) would spill
-        else return launch_ls<T, 1, SG_NLW1>(p, 1, st);
+        else {
+            static const bool no_wres = getenv("SRCGAN_NO_WRES") != nullptr;
+            // resident weights: two 40 KiB halo stages + nchunk * 18 KiB + bias within 160 KiB
+            if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) return launch_ls<T, 1, 8, true>(p, 1, st);
+            return launch_ls<T, 1, SG_NLW1>(p, 1, st);
+        }
     }
     const int ctiles = cdiv(p.Cout, 64);
     if (cfg == 'a') return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
