@@ -227,9 +227,17 @@ static int launch_wd(WdP p, hipStream_t st) {
 }
 
 template <typename T>
-static int dispatch_wd(const WdP& p, int mt, hipStream_t st, int& nsplit_used) {
+static int dispatch_wd(const WdP& p, int mt, int nt, hipStream_t st, int& nsplit_used) {
     constexpr bool F = std::is_same<T, float>::value;
     int rc = -1;
+    if (nt == 4) {
+        if constexpr (!F) {              // bf16 only: two f32 stages of 4 input planes exceed the LDS
+            switch (mt) {
+                case 1: rc = launch_wd<T, 1, 4, 4>(p, st); break;
+                case 2: rc = launch_wd<T, 2, 4, 4>(p, st); break;
+            }
+        }
+    } else
     switch (mt) {
         case 1: rc = launch_wd<T, 1, 2, F ? 2 : 4>(p, st); break;
         case 2: rc = launch_wd<T, 2, 2, F ? 2 : 4>(p, st); break;
@@ -241,13 +249,18 @@ static int dispatch_wd(const WdP& p, int mt, hipStream_t st, int& nsplit_used) {
     return 0;
 }
 
+// Input-channel tiles per workgroup: a row group of <= 64 gradient channels takes 4 (128 input channels, 8 waves)
+// instead of 2 -- the 2x2-wave form left one wave per SIMD (640 TFLOP/s against 1000 for the 4x2 form) and staged
+// the gradient planes once per 64 input channels.
+static int wd_nt(int mt, int cin_max, int dtype) { return (dtype == SRCGAN_BF16 && mt <= 2 && cin_max > 64) ? 4 : 2; }
+
 // pixel splits per row group: fill the chip once (workgroups resident per CU follow from the LDS tile)
-static int wd_nsplit(int mt, int ncit, int dtype, int B, int H, int W) {
+static int wd_nsplit(int mt, int nt, int ncit, int dtype, int B, int H, int W) {
     const int th = dtype == SRCGAN_F32 ? 2 : 4;
     const int pb = dtype == SRCGAN_F32 ? 128 : 64;
-    const long lds = 2 * ((long)mt * th * 32 * pb + 2L * (th + 2) * 34 * pb);
+    const long lds = 2 * ((long)mt * th * 32 * pb + (long)nt * (th + 2) * 34 * pb);
     int per_cu = (int)((160 * 1024) / lds); if (per_cu < 1) per_cu = 1;
-    if (per_cu * mt * 2 > 16) per_cu = 16 / (mt * 2) > 0 ? 16 / (mt * 2) : 1;      // <= 16 waves per CU
+    if (per_cu * mt * nt > 16) per_cu = 16 / (mt * nt) > 0 ? 16 / (mt * nt) : 1;      // <= 16 waves per CU
     const long ntiles = (long)B * cdiv(H, th) * cdiv(W, 32);
     long ns = (256L * per_cu) / ncit;
     if (ns > ntiles) ns = ntiles;
@@ -257,9 +270,12 @@ static int wd_nsplit(int mt, int ncit, int dtype, int B, int H, int W) {
 extern "C" size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, int H, int W) {
     size_t mx = 0;
     for (int g_base = 0; g_base < G; g_base += 128) {
-        const int rows = G - g_base < 128 ? G - g_base : 128, mt = cdiv(rows, 32), ncit = cdiv(C, 64);
-        const size_t b = (size_t)wd_nsplit(mt, ncit, dtype, B, H, W) * ncit * 10 * (32 * mt) * 64 * sizeof(float);
-        if (b > mx) mx = b;
+        const int rows = G - g_base < 128 ? G - g_base : 128, mt = cdiv(rows, 32);
+        for (int nt = 2; nt <= (dtype == SRCGAN_BF16 && mt <= 2 ? 4 : 2); nt += 2) {                 // either column-tile form may be chosen at run time
+            const int ncit = cdiv(C, 32 * nt);
+            const size_t b = (size_t)wd_nsplit(mt, nt, ncit, dtype, B, H, W) * ncit * 10 * (32 * mt) * (32 * nt) * sizeof(float);
+            if (b > mx) mx = b;
+        }
     }
     return mx;
 }
@@ -296,18 +312,21 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
         p.B = d->B; p.H = d->H; p.W = d->W; p.G = d->G; p.C = d->C;
         p.dycoff = d->dy_coff; p.xcoff = d->x_coff;
         p.dypix = (long)d->dy_cs * esz; p.dyplane = d->dy_plane ? d->dy_plane : 64; p.xpix = (long)d->x_cs * esz; p.xplane = d->x_plane ? d->x_plane : 64;
-        p.g_base = g_base; p.ncit = cdiv(cin_max, 64); p.want_bias = want_bias;
-        p.nsplit = wd_nsplit(mt, p.ncit, d->dtype, d->B, d->H, d->W);
+        static const bool nt2_only = getenv("SRCGAN_WD_NT2") != nullptr;
+        const int nt = nt2_only ? 2 : wd_nt(mt, cin_max, d->dtype);
+        p.g_base = g_base; p.ncit = cdiv(cin_max, 32 * nt); p.want_bias = want_bias;
+        p.nsplit = wd_nsplit(mt, nt, p.ncit, d->dtype, d->B, d->H, d->W);
         int ns = 0;
-        if (d->dtype == SRCGAN_F32) SG_TRY(dispatch_wd<float>(p, mt, st, ns));
-        else SG_TRY(dispatch_wd<__bf16>(p, mt, st, ns));
+        if (d->dtype == SRCGAN_F32) SG_TRY(dispatch_wd<float>(p, mt, nt, st, ns));
+        else SG_TRY(dispatch_wd<__bf16>(p, mt, nt, st, ns));
         WdRedP q;
         memset(&q, 0, sizeof(q));
         q.slab = d->slab; q.nsplit = ns; q.ncit = p.ncit; q.COT = 32 * mt; q.g_base = g_base; q.nseg = d->nseg; q.accumulate = d->accumulate;
         for (int k = 0; k < d->nseg; ++k) { q.seg[k].g0 = d->seg[k].g0; q.seg[k].g1 = d->seg[k].g1; q.seg[k].grad = d->seg[k].grad;
                                             q.seg[k].bias = d->seg[k].bias; q.seg[k].Cin = d->seg[k].Cin; q.seg[k].alpha = d->seg[k].alpha; }
-        const long per_split = (long)p.ncit * 10 * q.COT * 64;
-        hipLaunchKernelGGL(wgrad_dense_reduce_k<64>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
+        const long per_split = (long)p.ncit * 10 * q.COT * 32 * nt;
+        if (nt == 4) hipLaunchKernelGGL(wgrad_dense_reduce_k<128>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(wgrad_dense_reduce_k<64>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
         SG_LAUNCH_CHECK();
     }
     return 0;
