@@ -19,6 +19,7 @@ struct WdP {
     long dypix, dyplane, xpix, xplane;       // bytes; see conv_params.h (interleaved NHWC: plane = 64)
     int g_base;                 // first gradient channel of this launch's row group
     int nsplit, tiles_x, tiles_y, ntiles, ncit, want_bias;
+    unsigned long long* trace;       // diagnostic (SG_TRACE builds): per-tile-step timestamps of one workgroup
 };
 struct WdRedP {
     const float* slab; int nsplit, ncit, COT, g_base, nseg; WdSeg seg[8]; int accumulate;
@@ -163,6 +164,219 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path (image a whole number of tiles, operands < 2 GiB): the same tiling and LDS image, but
+//  * no per-piece address arithmetic: a wave's IPW per-lane offsets (relative to the tile origin) are computed once;
+//    a piece is `buffer_load_dwordx4 voff, rsrc(tile origin), soff(channel plane) offen lds`.  The halo pixels outside
+//    the image only occur in the first/last tile row/column: a 4-bit class per piece (8 pieces in one VGPR) ANDed with
+//    the tile's border mask swaps in an out-of-range offset, which the buffer range check zero-fills (3 VALU/piece);
+//  * the pieces of tile t+1 are issued from inside the MFMA loop of tile t, two per k-step, instead of in a block in
+//    front of it: a DMA issue costs ~60 cycles among MFMAs but ~150 in a block, during which the co-resident wave of
+//    the SIMD -- in lockstep through the barrier -- was issuing too, leaving the matrix pipe idle (the old form ran
+//    at 45-50 % MFMA utilisation: 11.4k cycles per tile step against 5.1k of MFMA).
+// Inline asm, not __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc (ROCm 7.2) treats the builtin as an LDS store that may
+// alias every later ds_read of the wave and puts `s_waitcnt vmcnt(0)` in front of the next fragment read -- the piece
+// had to LAND (~2 us) before the MFMA loop could go on (seen in the .s; the older waves of each SIMD ran at 50 %).
+// The compiler does not count asm memory operations: the loop waits `vmcnt(0)` by hand before its barrier.
+typedef int wd_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wd_dma16(const void* base, int voff, int soff, wd_lptr_t lds) {
+    const unsigned long long a = (unsigned long long)base;
+    wd_v4i rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    rs[2] = 0x7fffffff;
+    rs[3] = 0x00020000;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+}
+
+template <int MT, int NT, int TH>
+__global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) {
+    using T = __bf16;
+    using D = DT<T>;
+    constexpr int NW = MT * NT, TW = 32, NTAP = 9;
+    constexpr int IHT = TH + 2, IWT = TW + 2;
+    constexpr int PB = 64, PXP = 16;                                            // bytes per pixel of a plane; pixels per piece
+    constexpr int DPX = TH * TW, XPX = IHT * IWT;
+    constexpr int DPP = (DPX + PXP - 1) / PXP, XPP = (XPX + PXP - 1) / PXP;
+    constexpr int DBYTES = DPP * 1024, XBYTES = XPP * 1024;
+    constexpr int NPIECE = MT * DPP + NT * XPP, SBYTES = MT * DBYTES + NT * XBYTES;
+    constexpr int IPW = (NPIECE + NW - 1) / NW;
+    constexpr int OOB = 0x7fffffff;
+#ifndef SG_WD_PPK
+#define SG_WD_PPK 0
+#endif
+    constexpr int PPK = SG_WD_PPK ? SG_WD_PPK : 4;                              // pieces issued per group, from the first group on
+    static_assert(IPW <= 16, "piece classes are packed 4 bits each into two registers");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NT, wn = wave % NT;
+    // Workgroup -> (input-channel tile, pixel split).  Consecutive workgroup ids go round-robin over the 8 XCDs, so the
+    // ncit workgroups that read the SAME gradient tiles (same split, different cit) are given ids 8 apart: same XCD,
+    // dispatched together, and two of the three gradient reads hit that XCD's L2 (measured before: 1.4 GB fetched per
+    // launch against 0.67 GB of operands).
+    int cit, split;
+    {
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
+        const int xcd = L & 7, j = L >> 3;
+        const int full = (nwg >> 3) * 8;                       // ids below `full` fill whole rounds of 8 XCDs
+        // position in the XCD-major order: XCD k owns positions [k * per, (k + 1) * per)
+        const int per = nwg >> 3;
+        const int pos = L < full ? xcd * per + j : L;          // the ragged tail keeps its id
+        cit = pos % p.ncit; split = pos / p.ncit;
+        if (split >= p.nsplit) return;
+    }
+    const bool do_bias = wn == 0 && cit == 0 && p.want_bias;
+
+    // ---- per-wave piece table: per-lane offset from the tile origin, channel-plane offset (uniform), border class
+    int voff[IPW], soff[IPW];
+    unsigned cls[2] = {0u, 0u};
+    {
+        const int part = lane & 3, lpx = lane >> 2;
+#pragma unroll
+        for (int it = 0; it < IPW; ++it) {
+            const int pi = it * NW + wave;
+            int v = OOB, so = 0;
+            if (pi < MT * DPP) {
+                const int m = pi / DPP, pix = (pi - m * DPP) * PXP + lpx;
+                const int ch = p.g_base + m * 32 + part * D::EPP;
+                if (pix < DPX && ch < p.G) v = ((pix / TW) * p.W + pix % TW) * (int)p.dypix + part * 16;
+                so = (int)wd_chan_off<T>(p.dycoff + p.g_base + m * 32, p.dyplane);
+            } else if (pi < NPIECE) {
+                const int pj = pi - MT * DPP, n = pj / XPP, pix = (pj - n * XPP) * PXP + lpx;
+                const int iy = pix / IWT, ix = pix - iy * IWT;
+                const int ch = (cit * NT + n) * 32 + part * D::EPP;
+                if (pix < XPX && ch < p.C) v = (iy * p.W + ix) * (int)p.xpix + part * 16;
+                so = (int)wd_chan_off<T>(p.xcoff + (cit * NT + n) * 32, p.xplane);
+                cls[it / 8] |= (unsigned)((iy == 0) | ((iy == IHT - 1) << 1) | ((ix == 0) << 2) | ((ix == IWT - 1) << 3)) << (4 * (it % 8));
+            }
+            voff[it] = v; soff[it] = __builtin_amdgcn_readfirstlane(so);
+        }
+    }
+
+    f32x16 acc[NTAP + 1];
+#pragma unroll
+    for (int a = 0; a <= NTAP; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+    const int t_begin = (int)((long)p.ntiles * split / p.nsplit);
+    const int t_end = (int)((long)p.ntiles * (split + 1) / p.nsplit);
+    // tile decode, advanced with scalar carries
+    // tiles are walked column-wise (ty fastest): consecutive tiles share 2 of their TH+2 halo rows, just fetched -> L2
+    int ty = t_begin % p.tiles_y, tx = (t_begin / p.tiles_y) % p.tiles_x, tb = t_begin / (p.tiles_x * p.tiles_y);
+    tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tb = __builtin_amdgcn_readfirstlane(tb);
+    const char* dyo = nullptr; const char* xo = nullptr; unsigned clm[2] = {0u, 0u};
+    auto origin = [&]() {                 // operands of the tile (tb, ty, tx): uniform origins + this wave's masked classes
+        const long px = ((long)tb * p.H + ty * TH) * p.W + tx * TW;
+        dyo = (const char*)p.dy + px * p.dypix;
+        xo = (const char*)p.x + (px - p.W - 1) * p.xpix;
+        const unsigned m = (unsigned)((ty == 0) | ((ty == p.tiles_y - 1) << 1) | ((tx == 0) << 2) | ((tx == p.tiles_x - 1) << 3));
+        clm[0] = cls[0] & (m * 0x11111111u); clm[1] = cls[1] & (m * 0x11111111u);
+    };
+    auto advance = [&]() { if (++ty == p.tiles_y) { ty = 0; if (++tx == p.tiles_x) { tx = 0; ++tb; } } };
+    auto piece = [&](int it, int stage) __attribute__((always_inline)) {
+        const int pi = it * NW + wave;
+        if (IPW * NW != NPIECE && pi >= NPIECE) return;
+        const int v = ((clm[it / 8] >> (4 * (it % 8))) & 15u) ? OOB : voff[it];
+        wd_dma16(pi < MT * DPP ? dyo : xo, v, soff[it], (wd_lptr_t)(smem + stage * SBYTES + pi * 1024));
+    };
+
+    if (t_begin < t_end) {
+        origin();
+#pragma unroll
+        for (int it = 0; it < IPW; ++it) piece(it, 0);
+    }
+    const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
+    const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    int stage = 0;
+    for (int t = t_begin; t < t_end; ++t, stage ^= 1) {
+#ifdef SG_TRACE
+        const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        const unsigned long long t_land = __builtin_amdgcn_s_memrealtime();
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): own (asm-issued) DMAs of tile t landed
+        __syncthreads();            // everyone's landed; everyone is done with the other stage
+#ifdef SG_TRACE
+        if (p.trace && blockIdx.x == 1 && blockIdx.y == 3 && lane == 0 && t - t_begin >= 8 && t - t_begin < 12)
+            p.trace[160 + (t - t_begin - 8) * 8 + wave] = t_arr;
+        if (p.trace && blockIdx.x == 1 && blockIdx.y == 3 && wave == 0 && lane == 0 && t - t_begin < 40) {
+            p.trace[(t - t_begin) * 4 + 0] = t_arr; p.trace[(t - t_begin) * 4 + 1] = t_land; p.trace[(t - t_begin) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            p.trace[(t - t_begin) * 4 + 3] = __builtin_readcyclecounter();
+        }
+#endif
+        const bool more = t + 1 < t_end;
+        if (more) { advance(); origin(); }
+        const char* my_d = smem + stage * SBYTES + wm * DBYTES;
+        const char* my_x = smem + stage * SBYTES + MT * DBYTES + wn * XBYTES;
+        // Row-ordered: the TH*2 gradient fragments a[py][xh] of the tile are read once; an input fragment b(i, kx, xh)
+        // (input row i, tap column kx, pixel half xh) is read ONCE and feeds every (output row py, ky) with py + ky == i
+        // -- (TH+2)*3*2 = 36 input reads per tile instead of TH*9*2 = 72.  Reads run PD groups ahead of the MFMAs.
+#ifndef SG_WD_PD
+#define SG_WD_PD 4
+#endif
+        constexpr int NGRP = IHT * 3 * 2, PD = SG_WD_PD;
+        bf16x8 fa[TH][2], fb[PD + 1];
+        auto read_b = [&](int G) {
+            const int i2 = G / 6, kx = (G % 6) / 2, xh = G % 2;
+            const char* bb = my_x + (i2 * IWT + xh * 16 + 8 * h + qq + kx) * PB + choff;
+            fb[G % (PD + 1)] = tr_frag2(bb, bb + 4 * PB);
+        };
+#pragma unroll
+        for (int py = 0; py < TH; ++py)
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+                const char* ab = my_d + (py * TW + xh * 16 + 8 * h + qq) * PB + choff;
+                fa[py][xh] = tr_frag2(ab, ab + 4 * PB);
+            }
+#pragma unroll
+        for (int G = 0; G < PD; ++G) read_b(G);
+#pragma unroll
+        for (int G = 0; G < NGRP; ++G) {
+            if (G + PD < NGRP) read_b(G + PD);
+            if (more) {                                  // next tile's pieces ride in the shadow of this tile's MFMAs
+#pragma unroll
+                for (int j = 0; j < PPK; ++j)
+                    if (PPK * G + j < IPW) piece(PPK * G + j, stage ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int i2 = G / 6, kx = (G % 6) / 2, xh = G % 2;
+#pragma unroll
+            for (int py = 0; py < TH; ++py) {
+                const int ky = i2 - py;
+                if (ky < 0 || ky > 2) continue;
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx], 0, 0, 0);
+            }
+            // bias pseudo-tap: one MFMA per gradient fragment, placed in the single-MFMA groups of the first/last input row
+            if (do_bias && kx == 0 && (i2 == 0 || i2 == IHT - 1))
+#pragma unroll
+                for (int py = (i2 == 0 ? 0 : TH / 2); py < (i2 == 0 ? TH / 2 : TH); ++py)
+                    acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], ones, acc[NTAP], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    constexpr int COT = 32 * MT, CIT = 32 * NT;
+    float* sp = p.slab + ((size_t)split * p.ncit + cit) * (NTAP + 1) * COT * CIT;
+#pragma unroll
+    for (int tap = 0; tap <= NTAP; ++tap) {
+        if (tap == NTAP && !do_bias) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            sp[((size_t)tap * COT + row) * CIT + wn * 32 + r] = acc[tap][i];
+        }
+    }
+}
+
 // 64 slab elements x 4 split lanes per block; fixed order -> deterministic.  Scatter by segment.
 template <int CIT>
 __global__ __launch_bounds__(256) void wgrad_dense_reduce_k(const WdRedP p) {
@@ -204,23 +418,61 @@ static int launch_wd(WdP p, hipStream_t st) {
     constexpr int PB = 32 * (int)sizeof(T), PXP = 64 / (PB / 16);
     constexpr size_t SMEM = 2 * 1024 * ((size_t)MT * ((TH * 32 + PXP - 1) / PXP) + (size_t)NT * (((TH + 2) * 34 + PXP - 1) / PXP));
     static_assert(SMEM <= 160 * 1024, "wgrad_dense tile exceeds LDS");
-    auto kern = wgrad_dense_k<T, MT, NT, TH>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    void (*kern)(const WdP) = wgrad_dense_k<T, MT, NT, TH>;
+    bool fast = false;
+    if constexpr (!std::is_same<T, float>::value) {
+        // whole tiles, 32-channel-aligned slices when planar, and every byte offset within 31 bits
+        static const bool no_fast = getenv("SRCGAN_WD_SLOW") != nullptr;
+        const double span_dy = p.dyplane != 64 ? (double)p.dyplane * cdiv(p.dycoff + p.G, 32) : (double)p.B * p.H * p.W * p.dypix;
+        const double span_x = p.xplane != 64 ? (double)p.xplane * cdiv(p.xcoff + p.C, 32) : (double)p.B * p.H * p.W * p.xpix;
+        fast = !no_fast && p.H % TH == 0 && p.W % 32 == 0 && span_dy < 2.0e9 && span_x < 2.0e9 &&
+               (p.dyplane == 64 || (p.dycoff + p.g_base) % 32 == 0) && (p.xplane == 64 || p.xcoff % 32 == 0);
+        constexpr int IPWF = (MT * (TH * 2) + NT * (((TH + 2) * 34 + 15) / 16) + MT * NT - 1) / (MT * NT);      // pieces per wave
+        if constexpr (IPWF <= 10) { if (fast) kern = wgrad_dense_fast_k<MT, NT, TH>; }   // larger tables would spill beside 160 accumulators
+        else fast = false;
+    }
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fast]) {
         SG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_set = true;
+        attr_set[fast] = true;
     }
     p.tiles_x = cdiv(p.W, 32);
     p.tiles_y = cdiv(p.H, TH);
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
     char cls[96];
-    snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NT);
+    snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d%s>", sizeof(T) == 4 ? "f32" : "bf16", MT, NT, fast ? ",fast" : "");
     const double px = (double)p.B * p.H * p.W;
     const int rows = (p.G - p.g_base) < 32 * MT ? (p.G - p.g_base) : 32 * MT;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * rows * (double)(p.ncit * 32 * NT < p.C ? p.ncit * 32 * NT : p.C),
                                   px * (rows + p.C) * sizeof(T), st);
+#ifdef SG_TRACE
+    static unsigned long long* trace = nullptr;
+    if (!trace) SG_HIP(hipMalloc(&trace, 48 * 4 * 8));
+    SG_HIP(hipMemsetAsync(trace, 0, 48 * 4 * 8, st));
+    p.trace = trace;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ncit, (unsigned)p.nsplit), dim3(MT * NT * 64), SMEM, st, p);
+#ifdef SG_TRACE
+    {
+        static int dumps = 0;
+        if (getenv("SRCGAN_TRACE") && dumps < 2 && fast) {
+            ++dumps;
+            unsigned long long h[48 * 4];
+            SG_HIP(hipStreamSynchronize(st));
+            SG_HIP(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[trace] %s (10 ns ticks: arrive at barrier, own DMA landed, barrier exit)\n", cls);
+            for (int k = 0; k < 4; ++k) {
+                fprintf(stderr, "[trace] step %d arrivals by wave (rel. wave 0):", 8 + k);
+                for (int w = 0; w < 8; ++w) fprintf(stderr, " %5lld", (long long)(h[160 + k * 8 + w] - h[160 + k * 8]));
+                fprintf(stderr, "\n");
+            }
+            for (int k = 0; k < 40 && h[k * 4]; ++k)
+                fprintf(stderr, "[trace] %2d arrive %6lld landed %6lld exit %6lld  shader-clock %5.0f MHz\n", k, (long long)(h[k * 4] - h[0]), (long long)(h[k * 4 + 1] - h[0]), (long long)(h[k * 4 + 2] - h[0]),
+                        k ? (double)(h[k * 4 + 3] - h[(k - 1) * 4 + 3]) / (double)(h[k * 4 + 2] - h[(k - 1) * 4 + 2]) * 100.0 : 0.0);
+        }
+    }
+#endif
     sg_prof_stop(tok, st);
     SG_LAUNCH_CHECK();
     return p.nsplit;

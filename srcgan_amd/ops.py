@@ -139,18 +139,24 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, *, kh: int
     return grad
 
 
-def wgrad_dense(dy: torch.Tensor, x: torch.Tensor, segs, *, G: Optional[int] = None, Cc: Optional[int] = None) -> None:
-    """Dense-block weight gradient.  dy [B,H,W,>=G], x [B,H,W,>=C] NHWC; segs = [(g0, g1, grad|None, bias|None, Cin, alpha)]."""
+def wgrad_dense(dy: torch.Tensor, x: torch.Tensor, segs, *, G: Optional[int] = None, Cc: Optional[int] = None,
+                dy_plane: int = 0, x_plane: int = 0, shape: Optional[Tuple[int, int, int]] = None) -> None:
+    """Dense-block weight gradient.  dy [B,H,W,>=G], x [B,H,W,>=C] NHWC; segs = [(g0, g1, grad|None, bias|None, Cin, alpha)].
+    Blocked-layout operands (make_blocked) pass *_plane = plane stride in bytes, shape=(B,H,W) and explicit G / Cc."""
     N.require_cuda(x, "wgrad_dense")
     lib = N.lib()
     d = N.WgradDenseDesc()
-    B, H, W, dycs = dy.shape
+    if shape is not None:
+        (B, H, W), dycs = shape, dy.shape[-1]
+    else:
+        B, H, W, dycs = dy.shape
     G = G or dycs
-    Cc = Cc or x.shape[3]
+    Cc = Cc or x.shape[-1]
     dt = N.dtype_id(x.dtype)
     slab = torch.empty(lib.srcgan_wgrad_dense_slab_bytes(G, Cc, dt, B, H, W), dtype=torch.uint8, device=x.device)
     d.dy, d.x, d.slab, d.dtype = dy.data_ptr(), x.data_ptr(), slab.data_ptr(), dt
-    d.B, d.H, d.W, d.G, d.dy_cs, d.dy_coff, d.C, d.x_cs, d.x_coff = B, H, W, G, dycs, 0, Cc, x.shape[3], 0
+    d.B, d.H, d.W, d.G, d.dy_cs, d.dy_coff, d.C, d.x_cs, d.x_coff = B, H, W, G, dycs, 0, Cc, x.shape[-1], 0
+    d.dy_plane, d.x_plane = dy_plane, x_plane
     d.nseg = len(segs)
     for i, (g0, g1, grad, bias, cin, alpha) in enumerate(segs):
         d.seg[i].g0, d.seg[i].g1, d.seg[i].Cin, d.seg[i].alpha = g0, g1, cin, alpha
