@@ -221,7 +221,7 @@ __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, 
 // holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
 // 2.6 us per chunk against 1.2 us of MFMA), and the weights are 18 of the 57 KiB a stage moves.  Needs ctiles == 1 and
 // nchunk * 18 KiB + two halo stages within 160 KiB (Cin <= 128 in bf16).
-template <typename T, int MT, int NLW, bool WRES>
+template <typename T, int MT, int NLW, bool WRES, int EM>
 __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
     constexpr int NWV = 8, PT = 2;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #endif
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
             if (!(p.dbg & 4))
-                conv_epilogue_lds_rows<T, MT, PT>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
+                conv_epilogue_lds_rows<T, MT, PT, EM>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
 #ifdef SG_TRACE
             if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk <= 60) {
                 p.trace[(trk - 1) * 8 + 3] = t_pre; p.trace[(trk - 1) * 8 + 6] = t_eb; p.trace[(trk - 1) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -481,11 +481,11 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     }
 }
 
-template <typename T, int MT, int NLW, bool WRES = false>
+template <typename T, int MT, int NLW, bool WRES = false, int EM = 7>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
     constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
-    auto kern = conv3x3_ls_k<T, MT, NLW, WRES>;
+    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -501,7 +501,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "");
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "", EM);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -594,12 +594,27 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
         else {
             static const bool no_wres = getenv("SRCGAN_NO_WRES") != nullptr;
             // resident weights: two 40 KiB halo stages + nchunk * 18 KiB + bias within 160 KiB
-            if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) return launch_ls<T, 1, 8, true>(p, 1, st);
-            return launch_ls<T, 1, SG_NLW1>(p, 1, st);
+            // epilogue operand set: Cout <= 32 convs are the dense-block forward (none) and its gradient slices (mz)
+            const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0);
+            if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) {
+                if (em == 0) return launch_ls<T, 1, 8, true, 0>(p, 1, st);
+                if (em == 4) return launch_ls<T, 1, 8, true, 4>(p, 1, st);
+                return launch_ls<T, 1, 8, true, 7>(p, 1, st);
+            }
+            if (em == 0) return launch_ls<T, 1, SG_NLW1, false, 0>(p, 1, st);
+            if (em == 4) return launch_ls<T, 1, SG_NLW1, false, 4>(p, 1, st);
+            return launch_ls<T, 1, SG_NLW1, false, 7>(p, 1, st);
         }
     }
     const int ctiles = cdiv(p.Cout, 64);
     if (cfg == 'a') return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
+    if constexpr (sizeof(T) == 2) {
+        const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0);
+        if (em == 0) return launch_ls<T, 2, 4, false, 0>(p, ctiles, st);
+        if (em == 1) return launch_ls<T, 2, 4, false, 1>(p, ctiles, st);
+        if (em == 3) return launch_ls<T, 2, 4, false, 3>(p, ctiles, st);
+        if (em == 4) return launch_ls<T, 2, 4, false, 4>(p, ctiles, st);
+    }
     return launch_ls<T, 2, 4>(p, ctiles, st);
 }
 

@@ -239,7 +239,9 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x
 //  * the residual (r1) and activation-mask (mz) operands of ALL passes of a row are requested before the row's
 //    accumulators go through the LDS transposition, so one memory latency is exposed per row, not one per pass.
 // b, ct, oy0, ox0 must be wave-uniform.
-template <typename T, int MT, int PT>
+// EM: which optional operands this instantiation can take (1 = r1, 2 = r2, 4 = mz); the others compile away, with
+// their addressing and the scalar registers it pins (the all-operand form spills ~100 SGPRs and runs ~1000 instructions).
+template <typename T, int MT, int PT, int EM = 7>
 __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32x16 (&acc)[MT][PT], char* lds_wave, const char* lds_bias,
                                                        int b, int ct, int oy0, int ox0, int lane) {
     constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
@@ -256,7 +258,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
         const f32x4 bv = *(const f32x4*)(lds_bias + (co0 + i) * 4);
         bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3];
     }
-    const bool use_r1 = p.r1 && co0 < p.r1cend, use_r2 = p.r2 && co0 < p.r2cend, use_mz = p.mz && co0 >= p.mzc0;
+    const bool use_r1 = (EM & 1) && p.r1 && co0 < p.r1cend, use_r2 = (EM & 2) && p.r2 && co0 < p.r2cend, use_mz = (EM & 4) && p.mz && co0 >= p.mzc0;
     // per-lane byte offsets (pixel lx of a pass, channel co0): the same for every unit, row and pass
     const long lstep = (long)lx * p.os;
     const long ly = lstep * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane);
