@@ -76,10 +76,18 @@ def cpu_baseline(nb, lr_hw, up, threads, crop=256):
                       f"= {frac:.4f} of an image's pixels, fp32 torch CPU oracle, {dt:.1f} s; value = {frac:.4f}/{dt:.1f}s"}
 
 
+def _ints(text):
+    import re
+    return [int(t) for t in re.findall(r"(?<![\w.])\d+(?![\w.])", text)]
+
+
 def pmc_traffic(cls):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, separate --pmc runs of this same command: scripts/profile_round.sh).  PMC counters
-    cannot be read from inside the timed process, so this is the last profiled value or null."""
+    cannot be read from inside the timed process, so this is the last profiled value or null.
+    Matching a profiling class ("wgrad_dense<bf16,MT4,NT2,fast>") to a rocprof kernel name
+    ("void wgrad_dense_fast_k<4, 2, 4>(WdP)" or a mangled "_Z..Li4ELi2E..") goes by kernel base name and the leading
+    integer template arguments."""
     import glob, re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     if not files:
@@ -91,9 +99,17 @@ def pmc_traffic(cls):
     m = re.match(r"(\w+)<(\w+),(.*)>", cls)
     if not m:
         return None
-    base, mt = m.group(1), re.search(r"MT(\d)", cls)
-    for name, v in data.items():           # rocprof demangles template arguments inconsistently: match on kernel + MT
-        if base in name and (mt is None or re.search(rf"<[^,<>]+, {mt.group(1)}[,>]", name) or f"Li{mt.group(1)}E" in name):
+    base = m.group(1) + ("_fast" if ",fast" in cls else "") + "_k"
+    want = _ints(re.sub(r"[A-Za-z]+(?=\d)", " ", m.group(3).replace("W8+", "W").replace("x", " ")))
+    for name, v in data.items():
+        if base not in name:
+            continue
+        if name.startswith("_Z"):
+            have = [int(t) for t in re.findall(r"Li(\d+)E", name)]
+        else:
+            a = re.search(r"<(.*)>\(", name)
+            have = _ints(a.group(1)) if a else []
+        if have[:len(want)] == want or (want and not have):
             return v["hbm_bytes_per_launch"]
     return None
 
