@@ -283,3 +283,74 @@ def test_wgrad_dense_block(ops, dt, nf, gc, hw):
     ops.wgrad_dense(_nhwc(ops, Gd, Cc, dt), _nhwc(ops, A, Cc, dt), segs2)
     for (g0, g1, _, gb, cin, alpha), (rw, rb) in zip(segs2, refs):
         assert rel_err(gb.cpu(), rb) < TOL[dt]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Blocked (plane-major) layout of the dense-block buffers + the production kernel variants it selects
+# (loader-specialised 3x3 kernel with resident weights / operand-set specialisations, dense wgrad fast path).
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,hw", [(64, 32, (16, 32)), (128, 32, (33, 70)), (160, 32, (16, 64)), (192, 64, (20, 40))])
+def test_conv3x3_blocked_layout(ops, dt, cin, cout, hw):
+    """RDB conv on blocked buffers: forward (bias + LeakyReLU into the block's own slice when it fits, else residual form),
+    and the gradient-slice form (LeakyReLU' mask operand)."""
+    torch.manual_seed(21)
+    H, W = hw
+    B, Cc = 2, 192
+    buf = torch.rand(B, Cc, H, W) - 0.5
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    b = torch.randn(cout) * 0.1
+    wp = ops.pack_conv2d_fwd(w.cuda(), dt)
+    xq, wq = _q(buf, dt), _q(w, dt)
+    conv = F.conv2d(xq[:, :cin], wq, b, 1, 1)
+    db, pl = ops.make_blocked(_nhwc(ops, buf, Cc, dt))
+    if cin + cout <= Cc:
+        ops.conv_igemm(db, wp, db, kh=3, kw=3, Cin=cin, Cout=cout, y_coff=cin, pad=(1, 1), bias=b.cuda(), act=True,
+                       x_plane=pl, y_plane=pl, shape=(B, H, W))
+        got = ops.to_nchw(ops.from_blocked(db, Cc), cout, cin).cpu()
+        assert rel_err(got, F.leaky_relu(conv, 0.2)) < TOL[dt]
+    else:
+        y = torch.zeros(B, H, W, cout, device="cuda", dtype=db.dtype)
+        ops.conv_igemm(db, wp, y, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), bias=b.cuda(), alpha=0.2, r1=db, r1_cend=cout, beta1=1.0,
+                       x_plane=pl, r1_plane=pl, shape=(B, H, W))
+        assert rel_err(ops.to_nchw(y).cpu(), 0.2 * conv + xq[:, :cout]) < TOL[dt]
+    # mask operand: y = conv * LeakyReLU'(z), z = another slice of the same blocked buffer
+    db2, _ = ops.make_blocked(_nhwc(ops, buf, Cc, dt))
+    y2 = torch.zeros(B, H, W, cout, device="cuda", dtype=db2.dtype)
+    ops.conv_igemm(db2, wp, y2, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), mz=db2, mz_coff=Cc - cout, x_plane=pl, mz_plane=pl, shape=(B, H, W))
+    z = xq[:, Cc - cout:]
+    ref = F.conv2d(xq[:, :cin], wq, None, 1, 1) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.2))
+    assert rel_err(ops.to_nchw(y2).cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("blocked", [False, True])
+@pytest.mark.parametrize("hw", [(8, 64), (16, 32), (12, 96)])
+def test_wgrad_dense_production_tiles(ops, blocked, hw):
+    """nf=64, gc=32 in bf16 on whole tiles: the 128-row (4x2 waves) and 64-row (2x4 waves) fast-path kernels, first / interior /
+    last tile rows and columns, interleaved and blocked operands."""
+    torch.manual_seed(12)
+    dt, nf, gc = "bf16", 64, 32
+    H, W = hw
+    Cc = nf + 4 * gc
+    A = _q(torch.rand(2, Cc, H, W) - 0.5, dt)
+    Gd = _q(torch.rand(2, Cc, H, W) - 0.5, dt)
+    segs, refs = [], []
+    for m in (5, 4, 3, 2, 1):
+        g0 = 0 if m == 5 else nf + (4 - m) * gc
+        co = nf if m == 5 else gc
+        cin = nf + (m - 1) * gc
+        w = torch.zeros(co, cin, 3, 3, requires_grad=True)
+        b = torch.zeros(co, requires_grad=True)
+        F.conv2d(A[:, :cin], w, b, 1, 1).backward(Gd[:, g0:g0 + co])
+        segs.append((g0, g0 + co, torch.full((co, cin, 3, 3), 7.0, device="cuda"), torch.full((co,), 7.0, device="cuda"), cin, 1.0))
+        refs.append((w.grad, b.grad))
+    Gn, An = _nhwc(ops, Gd, Cc, dt), _nhwc(ops, A, Cc, dt)
+    if blocked:
+        Gb, pl = ops.make_blocked(Gn)
+        Ab, _ = ops.make_blocked(An)
+        ops.wgrad_dense(Gb, Ab, segs, G=Cc, Cc=Cc, dy_plane=pl, x_plane=pl, shape=(2, H, W))
+    else:
+        ops.wgrad_dense(Gn, An, segs)
+    for (g0, g1, gw, gb, cin, alpha), (rw, rb) in zip(segs, refs):
+        assert rel_err(gw.cpu(), rw) < TOL[dt], (g0, cin)
+        assert rel_err(gb.cpu(), rb) < TOL[dt], (g0, cin)
