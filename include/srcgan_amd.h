@@ -181,6 +181,14 @@ int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const
                               const void* mz, int mz_cs, int mz_coff, long mz_plane, float mslope, long npix, int C,
                               int dtype, void* stream);
 
+/* x2 nearest up-sampling of an NHWC feature map (src may be a channel slice of a blocked buffer: s_plane != 0) and its
+ * adjoint: dst[y][x] = sum of the 2x2 block of src, times LeakyReLU'(mz[y][x]) when mz is given.  Replaces
+ * F.interpolate(scale_factor=2, mode='nearest') and its backward in the legacy generators (model/model.py:384-386,428-433). */
+int srcgan_upsample2_nhwc(const void* src, int s_cs, int s_coff, long s_plane, void* dst, int d_cs,
+                          int B, int H, int W, int C, int dtype, void* stream);
+int srcgan_sum2x2_nhwc(const void* src, int s_cs, void* dst, int d_cs, const void* mz, int m_cs, float mslope,
+                       int B, int H, int W, int C, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Loss reductions on flat f32 arrays (replace aten::l1_loss / mse_loss and their
  * backward; losses.py:95-147, train.py:67-128).  out: device f32 scalar.
@@ -215,6 +223,11 @@ typedef struct srcgan_rddbnet_cfg {
     int dtype;
     int down;          /* 0: RDDBNet (LR->HR, deconv up-sampler).  >0: HR->LR mirror
                           ("RDDBNetA", build-defined): `down` = /2^k factor, strided 3x3 convs */
+    int legacy;        /* 0: rddb.py RDDBNet.  1: model/model.py:394-440 RDDBNetB (G_A of train.py:172): nearest x2 +
+                          upconv1/upconv2, HRconv applied 8 times, conv_last with bias; `up` = 2 ('x2': upconv1 twice) or
+                          4 ('x4').  2: model/model.py:347-391 legacy RDDBNet (its trunk result is discarded by the
+                          reference's forward: not computed, no gradients); `up` = 1, 2 or 4.
+                          params/grads follow the respective state_dict order. */
 } srcgan_rddbnet_cfg;
 int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);
 size_t srcgan_rddbnet_ws_bytes(const srcgan_rddbnet_cfg* c);        /* forward workspace (kept for backward) */

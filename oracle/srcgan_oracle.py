@@ -32,6 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys",
 ]
 
 
@@ -77,6 +78,59 @@ def rddbnet_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
         for s in range(int(math.log2(upscale_factor))):
             fea = _lrelu(F.conv_transpose2d(fea, sd[f"upscale_layers.{2 * s}.weight"], None, 2, 0))
     return F.conv2d(fea, sd["conv_last.weight"], None, 1, 1)
+
+
+def rddbnetb_forward(sd: State, x: Tensor, mode: str) -> Tensor:
+    """Legacy RDDBNetB.forward, model/model.py:417-440 (G_A of train.py:172,177): nearest x2 + upconv1 / upconv2,
+    HRconv applied eight times (shared weights), conv_last with bias.  Modes other than 'x2' / 'x4' leave the resolution
+    unchanged in the reference (no branch taken)."""
+    nb = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("RRDB_trunk."))
+    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    t = fea
+    for i in range(nb):
+        t = rrdb_forward(sd, f"RRDB_trunk.{i}.", t)
+    fea = fea + F.conv2d(t, sd["trunk_conv.weight"], sd["trunk_conv.bias"], 1, 1)
+    up = lambda z: F.interpolate(z, scale_factor=2, mode="nearest")
+    c = lambda name, z: _lrelu(F.conv2d(z, sd[name + ".weight"], sd[name + ".bias"], 1, 1))
+    if mode == "x4":
+        fea = c("upconv1", up(fea))
+        fea = c("upconv2", up(fea))
+    elif mode == "x2":
+        fea = c("upconv1", up(fea))
+        fea = c("upconv1", fea)
+    for _ in range(8):
+        fea = c("HRconv", fea)
+    return F.conv2d(fea, sd["conv_last.weight"], sd["conv_last.bias"], 1, 1)
+
+
+def legacy_rddbnet_forward(sd: State, x: Tensor, mode: str) -> Tensor:
+    """Legacy RDDBNet.forward, model/model.py:381-391: the trunk result is computed and DISCARDED there, so the output
+    does not depend on the RRDB / trunk_conv parameters (restated without the dead computation)."""
+    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    up = lambda z: F.interpolate(z, scale_factor=2, mode="nearest")
+    c = lambda name, z: _lrelu(F.conv2d(z, sd[name + ".weight"], sd[name + ".bias"], 1, 1))
+    if mode == "x4":
+        fea = c("upconv", up(fea))
+        fea = c("upconv", up(fea))
+    elif mode == "x2":
+        fea = c("upconv", up(fea))
+    elif mode == "x1":
+        fea = c("upconv", fea)
+    fea = c("HRconv", fea)
+    return F.conv2d(c("HRconv", fea), sd["conv_last.weight"], sd["conv_last.bias"], 1, 1)
+
+
+def legacy_keys(nb: int, tail) -> List[str]:
+    """state_dict key order of the legacy generators (tail = ('upconv1','upconv2','HRconv') or ('upconv','HRconv'))."""
+    keys = ["conv_first.weight", "conv_first.bias"]
+    for i in range(nb):
+        for j in (1, 2, 3):
+            for k in range(1, 6):
+                keys += [f"RRDB_trunk.{i}.RDB{j}.conv{k}.weight", f"RRDB_trunk.{i}.RDB{j}.conv{k}.bias"]
+    keys += ["trunk_conv.weight", "trunk_conv.bias"]
+    for t in tail:
+        keys += [t + ".weight", t + ".bias"]
+    return keys + ["conv_last.weight", "conv_last.bias"]
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:
@@ -381,8 +435,10 @@ def paired_step(st: PairedStepState, x: Tensor, y: Tensor) -> Dict[str, float]:
 class CycleState:
     def __init__(self, ga: State, gb: State, da: State, db: State, up: int, pool_size: int = 4,
                  lr: float = 1e-4, lr_d: float = 1e-5, beta1: float = 0.5,
-                 lambda_a: float = 10.0, lambda_b: float = 10.0, lambda_idt: float = 1.0, seed: int = 0):
+                 lambda_a: float = 10.0, lambda_b: float = 10.0, lambda_idt: float = 1.0, seed: int = 0,
+                 ga_kind: str = "rddbnet"):
         self.up = up
+        self.ga_kind = ga_kind          # "rddbnet" (rddb.py) or "rddbnetb" (model/model.py:394, what train.py:172 constructs)
         self.lam = (lambda_a, lambda_b, lambda_idt)
         req = lambda sd: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
                           for k, v in sd.items()}
@@ -402,7 +458,7 @@ def make_cycle_state(up=2, nf=64, nb=1, gc=32, ndf=64, n_layers=3, seed=0) -> Cy
 
 def cycle_step(st: CycleState, real_a: Tensor, real_b: Tensor) -> Dict[str, float]:
     la, lb, lidt = st.lam
-    GA = lambda t: rddbnet_forward(st.ga, t, st.up)
+    GA = (lambda t: rddbnetb_forward(st.ga, t, f"x{st.up}")) if st.ga_kind == "rddbnetb" else (lambda t: rddbnet_forward(st.ga, t, st.up))
     GB = lambda t: rddbneta_forward(st.gb, t, st.up)
     # forward, train.py:228-249 (opt.net == '1' branch: 3-channel both sides, nearest resampling)
     fake_b = GA(real_a); recl_a = GB(fake_b)

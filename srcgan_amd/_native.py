@@ -81,7 +81,7 @@ class WgradDenseDesc(C.Structure):
 
 class RddbCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("up", C.c_int), ("nf", C.c_int), ("nb", C.c_int), ("gc", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("down", C.c_int)]
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("down", C.c_int), ("legacy", C.c_int)]
 
 
 class NLayerDCfg(C.Structure):
@@ -115,6 +115,8 @@ SIGNATURES = {
     "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
     "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
+    "srcgan_upsample2_nhwc": (_I, [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "srcgan_sum2x2_nhwc": (_I, [_P, _I, _P, _I, _P, _I, _F, _I, _I, _I, _I, _I, _P]),
     "srcgan_loss_scratch_floats": (_I, []),
     "srcgan_loss_fwd": (_I, [_I, _P, _P, _F, _L, _P, _P, _P]),
     "srcgan_loss_bwd": (_I, [_I, _P, _P, _F, _L, _P, _F, _P, _P]),

@@ -655,6 +655,88 @@ extern "C" int srcgan_bilinear_down(const float* src, float* dst, int B, int C, 
     return 0;
 }
 
+// ---- x2 nearest up-sampling of an NHWC feature map and its adjoint (legacy generators, model/model.py:384-386,428-433:
+// F.interpolate(scale_factor=2, mode='nearest') between 3x3 convolutions).  16-byte vectors along the channels.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_nhwc_k(const T* __restrict__ src, int s_cs, int s_coff, long s_plane,
+                                                        T* __restrict__ dst, int d_cs, int H, int W, int C, long nvec) {
+    constexpr int EPP = DT<T>::EPP, KCE = DT<T>::KCE;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int vpc = C / EPP;                                  // vectors per output pixel
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int v = (int)(e % vpc); long q = e / vpc;
+        const int ox = (int)(q % (2 * W)); q /= 2 * W;
+        const int oy = (int)(q % (2 * H)); const long b = q / (2 * H);
+        const long ip = (b * H + (oy >> 1)) * W + (ox >> 1);
+        const int c = s_coff + v * EPP;
+        const char* sp = s_plane ? (const char*)src + ip * 64 + (long)(c / KCE) * s_plane + (c % KCE) * sizeof(T)
+                                 : (const char*)(src + ip * s_cs + c);
+        *(vecT*)(dst + ((b * 2 * H + oy) * 2 * W + ox) * (long)d_cs + v * EPP) = *(const vecT*)sp;
+    }
+}
+// dst[y][x] = sum of the 2x2 block of src, optionally times LeakyReLU'(mz[y][x]) (mz = the activated tensor that was up-sampled)
+template <typename T>
+__global__ __launch_bounds__(256) void sum2x2_nhwc_k(const T* __restrict__ src, int s_cs, T* __restrict__ dst, int d_cs,
+                                                     const T* __restrict__ mz, int m_cs, float mslope, int H, int W, int C, long nvec) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int vpc = C / EPP;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int v = (int)(e % vpc); long q = e / vpc;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H); const long b = q / H;
+        float acc[EPP];
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const vecT t = *(const vecT*)(src + ((b * 2 * H + 2 * y + a) * 2 * W + 2 * x + bb) * (long)s_cs + v * EPP);
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) acc[i] += to_f(t[i]);
+            }
+        const long op = (b * H + y) * W + x;
+        if (mz) {
+            const vecT m = *(const vecT*)(mz + op * m_cs + v * EPP);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) acc[i] *= to_f(m[i]) > 0.f ? 1.f : mslope;
+        }
+        vecT o;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(acc[i]);
+        *(vecT*)(dst + op * d_cs + v * EPP) = o;
+    }
+}
+extern "C" int srcgan_upsample2_nhwc(const void* src, int s_cs, int s_coff, long s_plane, void* dst, int d_cs,
+                                     int B, int H, int W, int C, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "srcgan_upsample2_nhwc: bad arguments");
+    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "srcgan_upsample2_nhwc: bad dtype %d", dtype);
+    const int epp = dtype == SRCGAN_F32 ? 4 : 8;
+    SG_REQUIRE(C % epp == 0 && s_cs % epp == 0 && s_coff % epp == 0 && d_cs % epp == 0 && C <= d_cs, "srcgan_upsample2_nhwc: channel counts/strides must be multiples of %d", epp);
+    const long nvec = (long)B * 4 * H * W * (C / epp);
+    if (dtype == SRCGAN_F32)
+        hipLaunchKernelGGL(upsample2_nhwc_k<float>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)src, s_cs, s_coff, s_plane, (float*)dst, d_cs, H, W, C, nvec);
+    else
+        hipLaunchKernelGGL(upsample2_nhwc_k<__bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, s_cs, s_coff, s_plane, (__bf16*)dst, d_cs, H, W, C, nvec);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int srcgan_sum2x2_nhwc(const void* src, int s_cs, void* dst, int d_cs, const void* mz, int m_cs, float mslope,
+                                  int B, int H, int W, int C, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "srcgan_sum2x2_nhwc: bad arguments");
+    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "srcgan_sum2x2_nhwc: bad dtype %d", dtype);
+    const int epp = dtype == SRCGAN_F32 ? 4 : 8;
+    SG_REQUIRE(C % epp == 0 && s_cs % epp == 0 && d_cs % epp == 0 && (!mz || m_cs % epp == 0), "srcgan_sum2x2_nhwc: channel counts/strides must be multiples of %d", epp);
+    const long nvec = (long)B * H * W * (C / epp);
+    if (dtype == SRCGAN_F32)
+        hipLaunchKernelGGL(sum2x2_nhwc_k<float>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)src, s_cs, (float*)dst, d_cs, (const float*)mz, m_cs, mslope, H, W, C, nvec);
+    else
+        hipLaunchKernelGGL(sum2x2_nhwc_k<__bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, s_cs, (__bf16*)dst, d_cs, (const __bf16*)mz, m_cs, mslope, H, W, C, nvec);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 // nearest resize, torch 'nearest' rule: src = floor(dst * in/out)
 __global__ __launch_bounds__(256) void nearest_resize_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
                                                         int OH, int OW, long total) {

@@ -61,7 +61,7 @@ struct Bump {   // workspace bump allocator (256-byte aligned)
 
 static int wgrad_call(int dtype, TRef dy, int OH, int OW, int Cout, TRef x, int B, int H, int W, int Cin, int kh, int kw,
                       int stride, int pad_y, int pad_x, WLayout lay, float alpha, float* slab, float* grad, void* st,
-                      float* bias_grad = nullptr) {
+                      float* bias_grad = nullptr, int accumulate = 0) {
     srcgan_wgrad_desc d;
     memset(&d, 0, sizeof(d));
     d.dy = dy.p; d.dy_cs = dy.cs; d.dy_coff = dy.coff; d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff;
@@ -69,7 +69,7 @@ static int wgrad_call(int dtype, TRef dy, int OH, int OW, int Cout, TRef x, int 
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.OH = OH; d.OW = OW; d.Cout = Cout; d.pad_y = pad_y; d.pad_x = pad_x;
     d.nsplit = srcgan_conv_wgrad_nsplit(B, OH, OW, Cout, Cin, stride);
     d.sr = lay.sr; d.sk = lay.sk; d.sty = lay.sty; d.stx = lay.stx; d.off = lay.off;
-    d.alpha = alpha; d.accumulate = 0;
+    d.alpha = alpha; d.accumulate = accumulate;
     return srcgan_conv_wgrad(&d, st);
 }
 static size_t wgrad_slab(int B, int OH, int OW, int Cout, int Cin, int kh, int kw, int stride) {
@@ -131,6 +131,10 @@ struct RddbPlan {
     size_t w_dn_f[5], w_dn_d[5][4];
     // parameter indices
     int p_first_w, p_first_b, p_rdb0, p_trunk_w, p_trunk_b, p_up0, p_dn0, p_last_w;
+    // legacy generators (model/model.py:347-440): tail = nearest x2 / shared 3x3 convs + LeakyReLU, conv_last with bias
+    int legacy, ntail, nlw, p_lg[3], p_last_b;
+    struct TailOp { int conv, w, hin, win, hout, wout; size_t out; } tail[16];     // conv: 1 = 3x3 conv w + LReLU, 0 = nearest x2
+    size_t lw_f[3], lw_d[3];
 };
 
 static int log2i(int v) { int n = 0; while ((1 << n) < v) ++n; return n; }
@@ -144,6 +148,10 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     SG_REQUIRE(c->up >= 1 && (c->up & (c->up - 1)) == 0 && c->up <= 16, "rddbnet: upscale_factor must be a power of two <= 16");
     SG_REQUIRE(c->down >= 0 && (c->down == 0 || ((c->down & (c->down - 1)) == 0 && c->down <= 16)), "rddbnet: bad down factor");
     SG_REQUIRE(!(c->down > 1 && c->up > 1), "rddbnet: up and down are exclusive");
+    SG_REQUIRE(c->legacy >= 0 && c->legacy <= 2, "rddbnet: legacy must be 0, 1 or 2");
+    SG_REQUIRE(c->legacy == 0 || (c->down == 0 && (c->up == 2 || c->up == 4 || (c->legacy == 2 && c->up == 1))),
+               "rddbnet: legacy generators take mode x2 / x4 (legacy RDDBNet also x1) and no down factor");
+    P.legacy = c->legacy; P.ntail = 0; P.nlw = 0;
     P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
     P.nf = c->nf; P.gc = c->gc; P.nb = c->nb; P.C = c->nf + 4 * c->gc;
     P.B = c->B; P.H = c->H; P.W = c->W;
@@ -162,9 +170,29 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     // and of the dense wgrad is then >= 1 KiB contiguous (64-byte pieces at a 384-byte pixel stride ran at half rate)
     P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
     P.szA = align_up((size_t)P.nplane * P.plane_bytes, 256);
-    P.A = b.take(P.szA * 3 * c->nb);
+    P.A = b.take(P.szA * (c->legacy == 2 ? 1 : 3 * c->nb));        // legacy RDDBNet discards its trunk: one buffer holds conv_first's output
     P.T = b.take(B * P.Ht * P.Wt * c->nf * e);
-    for (int s = 0; s <= P.nst; ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    for (int s = 0; s <= (c->legacy ? 0 : P.nst); ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    if (c->legacy) {
+        int h = P.Ht, w = P.Wt;
+        auto op = [&](int conv, int wi) {
+            RddbPlan::TailOp& o = P.tail[P.ntail++];
+            o.conv = conv; o.w = wi; o.hin = h; o.win = w;
+            if (!conv) { h *= 2; w *= 2; }
+            o.hout = h; o.wout = w; o.out = b.take(B * h * w * c->nf * e);
+        };
+        if (c->legacy == 1) {           // RDDBNetB (model.py:427-439): weights 0 = upconv1, 1 = upconv2, 2 = HRconv
+            if (c->up == 4) { op(0, 0); op(1, 0); op(0, 0); op(1, 1); }
+            else { op(0, 0); op(1, 0); op(1, 0); }
+            for (int k = 0; k < 8; ++k) op(1, 2);
+            P.nlw = 3;
+        } else {                        // legacy RDDBNet (model.py:381-391): weights 0 = upconv, 1 = HRconv
+            for (int t = 1; t < c->up; t *= 2) { op(0, 0); op(1, 0); }
+            if (c->up == 1) op(1, 0);
+            op(1, 1); op(1, 1);
+            P.nlw = 2;
+        }
+    }
     P.out = b.take(B * P.HO * P.WO * P.out_cs * e);
     P.wpk = b.off;
     Bump wb;
@@ -180,6 +208,7 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     P.w_trunk_f = pk(c->nf, c->nf, 9); P.w_trunk_d = pk(c->nf, c->nf, 9);
     for (int s = 0; s < P.nst; ++s) { for (int q = 0; q < 4; ++q) P.w_up_f[s][q] = pk(c->nf, c->nf, 1); P.w_up_d[s] = pk(c->nf, c->nf, 4); }
     P.w_last_f = pk(c->out_ch, c->nf, 9); P.w_last_d = pk(c->nf, P.out_cs, 9);
+    for (int k = 0; k < P.nlw; ++k) { P.lw_f[k] = pk(c->nf, c->nf, 9); P.lw_d[k] = pk(c->nf, c->nf, 9); }
     // dense-block backward: slice j of the block input gets its gradient from ONE conv over the concatenated
     // output-gradients [dy5 | dy4 | ... | dy_{j+1}] (rows = slice channels, K = nf + (4-j)*gc)
     P.w_rdb_d0 = wb.off;
@@ -193,8 +222,10 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     P.p_dn0 = n; n += 2 * P.ndn;
     P.p_rdb0 = n; n += c->nb * 30;
     P.p_trunk_w = n++; P.p_trunk_b = n++;
-    P.p_up0 = n; n += P.nst;
+    if (c->legacy) { P.p_up0 = n; for (int k = 0; k < P.nlw; ++k) { P.p_lg[k] = n; n += 2; } }
+    else { P.p_up0 = n; n += P.nst; }
     P.p_last_w = n++;
+    P.p_last_b = c->legacy ? n++ : -1;
     P.nparams = n;
     return 0;
 }
@@ -212,7 +243,8 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     const size_t e = P.esz, B = c->B;
     Bump b;
     Q.dout = b.take(B * P.HO * P.WO * P.out_cs * e);
-    for (int s = 0; s <= P.nst; ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    for (int s = 0; s <= (P.legacy ? 0 : P.nst); ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    if (P.legacy) { Q.dU[1] = b.take(B * P.HO * P.WO * c->nf * e); Q.dU[2] = b.take(B * P.HO * P.WO * c->nf * e); }   // ping-pong
     Q.dT = b.take(B * P.Ht * P.Wt * c->nf * e);
     Q.szP = align_up((size_t)P.nplane * P.plane_bytes, 256);
     for (int i = 0; i < 3; ++i) Q.Pg[i] = b.take(Q.szP);
@@ -223,7 +255,8 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     mx(wgrad_slab(c->B, c->H, c->W, c->nf, P.in_cs, 3, 3, 1));
     for (int k = 0; k < 5; ++k) mx(wgrad_slab(c->B, P.Ht, P.Wt, k < 4 ? c->gc : c->nf, c->nf + k * c->gc, 3, 3, 1));
     mx(wgrad_slab(c->B, P.Ht, P.Wt, c->nf, c->nf, 3, 3, 1));
-    for (int s = 0; s < P.nst; ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
+    for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
+    for (int k = 0; k < P.ntail; ++k) if (P.tail[k].conv) mx(wgrad_slab(c->B, P.tail[k].hout, P.tail[k].wout, c->nf, c->nf, 3, 3, 1));
     for (int s = 0; s < P.ndn; ++s) mx(wgrad_slab(c->B, c->H >> (s + 1), c->W >> (s + 1), c->nf, c->nf, 3, 3, 2));
     mx(wgrad_slab(c->B, P.HO, P.WO, c->out_ch, c->nf, 3, 3, 1));
     mx(srcgan_wgrad_dense_slab_bytes(P.C, P.C, c->dtype, c->B, P.Ht, P.Wt));
@@ -262,12 +295,14 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
             packs.add(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0);
         }
     packs.add(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
-    for (int s = 0; s < P.nst; ++s)
+    for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s)
         for (int q = 0; q < 4; ++q)   // ConvTranspose2d weight [ci][co][2][2]; parity (a,b) = q: rows = co, k = ci
             packs.add(params[P.p_up0 + s], wp + P.w_up_f[s][q], nf, nf, 1, 1, 4, (long)nf * 4, 0, 0, q);
+    for (int k = 0; k < P.nlw; ++k)
+        packs.add(params[P.p_lg[k]], wp + P.lw_f[k], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     packs.add(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
 
-    SG_TRY(packs.run("rddb_fwd", params[0], st));
+    SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : "rddb_fwd", params[0], st));
 
     // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -285,8 +320,8 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
                    .out(o, c->H >> (s + 1), c->W >> (s + 1), nf).pad(1, 1).lrelu().run(st));
         fea = o;
     }
-    // RRDB trunk (rddb.py:62-68,78-82)
-    for (int i = 0; i < c->nb; ++i) {
+    // RRDB trunk (rddb.py:62-68,78-82).  The legacy RDDBNet computes it and throws it away (model.py:382-383): skipped.
+    for (int i = 0; i < (P.legacy == 2 ? 0 : c->nb); ++i) {
         for (int j = 0; j < 3; ++j) {
             const int r = i * 3 + j;
             TRef A = Abuf(r);
@@ -306,8 +341,28 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
         }
     }
     // trunk_conv + global skip (rddb.py:109-110)
-    SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.T, nf), B, H, W, nf).w(wp + P.w_trunk_f, params[P.p_trunk_b]).out(T_(P.U[0], nf), H, W, nf)
-               .pad(1, 1).res1(trunk_in, nf, 1.f).run(st));
+    if (P.legacy != 2)
+        SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.T, nf), B, H, W, nf).w(wp + P.w_trunk_f, params[P.p_trunk_b]).out(T_(P.U[0], nf), H, W, nf)
+                   .pad(1, 1).res1(trunk_in, nf, 1.f).run(st));
+    if (P.legacy) {
+        // legacy tail (model.py:384-390, 427-439): [nearest x2 -> 3x3 conv -> LeakyReLU] stages, HRconv applied repeatedly
+        TRef cur = P.legacy == 2 ? trunk_in : T_(P.U[0], nf);
+        for (int k = 0; k < P.ntail; ++k) {
+            const RddbPlan::TailOp& o = P.tail[k];
+            TRef dst = T_(o.out, nf);
+            if (o.conv)
+                SG_TRY(Conv(dt, 3, 3, 1).in(cur, B, o.hin, o.win, nf).w(wp + P.lw_f[o.w], params[P.p_lg[o.w] + 1]).out(dst, o.hout, o.wout, nf)
+                           .pad(1, 1).lrelu().run(st));
+            else
+                SG_TRY(srcgan_upsample2_nhwc(cur.p, cur.cs, cur.coff, cur.plane, dst.p, dst.cs, B, o.hin, o.win, nf, dt, st));
+            cur = dst;
+        }
+        SG_HIP(hipMemsetAsync(w8 + P.out, 0, (size_t)B * P.HO * P.WO * P.out_cs * P.esz, (hipStream_t)st));
+        SG_TRY(Conv(dt, 3, 3, 1).in(cur, B, P.HO, P.WO, nf).w(wp + P.w_last_f, params[P.p_last_b]).out(T_(P.out, P.out_cs), P.HO, P.WO, c->out_ch)
+                   .pad(1, 1).run(st));
+        SG_TRY(srcgan_nhwc_to_nchw_f32(w8 + P.out, y_nchw, B, c->out_ch, P.HO, P.WO, P.out_cs, 0, dt, st));
+        return 0;
+    }
     // up-sampler: ConvTranspose2d(k2,s2) + LeakyReLU == 4 x (1x1 conv -> stride-2 scatter) (rddb.py:93-97,111-112)
     for (int s = 0; s < P.nst; ++s) {
         const int h = H << s, w = W << s;
@@ -345,11 +400,13 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         PackList packs(dt, wp);
         const WLayout L = lay_dgrad_s1(nf, 3, 3);
         packs.add(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
-        for (int s = 0; s < P.nst; ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
+        for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
             packs.add(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0);
+        for (int k = 0; k < P.nlw; ++k)
+            packs.add(params[P.p_lg[k]], wp + P.lw_d[k], nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         packs.add(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         SG_HIP(hipMemsetAsync(wp + P.w_rdb_d0, 0, P.w_rdb_dsz, (hipStream_t)st));
-        for (int r = 0; r < c->nb * 3; ++r) {
+        for (int r = 0; r < (P.legacy == 2 ? 0 : c->nb * 3); ++r) {
             const float a5 = (r % 3 == 2) ? 0.04f : 0.2f;       // d(x5)/d(block out), RDB3 carries the RRDB 0.2 too
             for (int j = 0; j < 5; ++j) {
                 const int rows = j == 0 ? nf : gc, ss = j == 0 ? 0 : nf + (j - 1) * gc, ktot = nf + (4 - j) * gc;
@@ -373,12 +430,60 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             const WLayout L0 = lay_dgrad_s1(c->in_ch, 3, 3);
             packs.add(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off);
         }
-        SG_TRY(packs.run(dx_nchw ? "rddb_bwd_dx" : "rddb_bwd", params[0], st));
+        SG_TRY(packs.run(P.legacy == 1 ? (dx_nchw ? "rddbB_bwd_dx" : "rddbB_bwd") : P.legacy == 2 ? (dx_nchw ? "rddbL_bwd_dx" : "rddbL_bwd")
+                                       : (dx_nchw ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st));
     }
 
     // ---- dy: NCHW f32 -> NHWC
     TRef dout = S_(Q.dout, P.out_cs);
     SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dout.p, B, c->out_ch, P.HO, P.WO, P.out_cs, dt, st));
+    TRef dU0 = S_(Q.dU[0], nf);
+    if (P.legacy) {
+        // ---- legacy tail backward.  dcur = gradient w.r.t. an op's output, already times LeakyReLU' of that output.
+        TRef tin = P.legacy == 2 ? Abuf(0) : T_(P.U[0], nf);          // tail input (not an activation output)
+        auto obuf = [&](int k) { return k < 0 ? tin : T_(P.tail[k].out, nf); };
+        TRef Fl = obuf(P.ntail - 1);
+        if (G(P.p_last_w))
+            SG_TRY(wgrad_call(dt, dout, P.HO, P.WO, c->out_ch, Fl, B, P.HO, P.WO, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_last_w), st, G(P.p_last_b)));
+        else if (G(P.p_last_b)) SG_TRY(bias_grad(dt, dout, (long)B * P.HO * P.WO, c->out_ch, 1.f, G(P.p_last_b), colscr, st));
+        int pp = 0;
+        auto nextbuf = [&](int k_in) { if (k_in < 0) return dU0; pp ^= 1; return S_(Q.dU[1 + pp], nf); };   // k_in: index of the op whose output gets this gradient
+        TRef dcur = nextbuf(P.ntail - 1);
+        {
+            Conv cv(dt, 3, 3, 1);
+            cv.in(dout, B, P.HO, P.WO, P.out_cs).w(wp + P.w_last_d).out(dcur, P.HO, P.WO, nf).pad(1, 1);
+            if (P.ntail > 0 && P.tail[P.ntail - 1].conv) cv.mask(Fl, 0);
+            SG_TRY(cv.run(st));
+        }
+        bool seen[3] = {false, false, false};
+        for (int k = P.ntail - 1; k >= 0; --k) {
+            const RddbPlan::TailOp& o = P.tail[k];
+            TRef xin_k = obuf(k - 1);
+            const bool in_act = k > 0 && P.tail[k - 1].conv;          // the op's input is a LeakyReLU output
+            TRef dst = nextbuf(k - 1);
+            if (o.conv) {
+                const int pw = P.p_lg[o.w];
+                if (G(pw)) SG_TRY(wgrad_call(dt, dcur, o.hout, o.wout, nf, xin_k, B, o.hin, o.win, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(pw), st, G(pw + 1), seen[o.w] ? 1 : 0));
+                else if (G(pw + 1)) SG_REQUIRE(false, "rddbnet (legacy): a shared convolution's bias gradient needs its weight gradient too");
+                seen[o.w] = true;
+                Conv cv(dt, 3, 3, 1);
+                cv.in(dcur, B, o.hout, o.wout, nf).w(wp + P.lw_d[o.w]).out(dst, o.hin, o.win, nf).pad(1, 1);
+                if (in_act) cv.mask(xin_k, 0);
+                SG_TRY(cv.run(st));
+            } else {
+                // nearest x2 backward = 2x2 block sums; the up-sampled tensor's own LeakyReLU' (if any) is applied at its resolution
+                SG_REQUIRE(xin_k.plane == 0 || !in_act, "rddbnet (legacy): unexpected blocked activation");
+                SG_TRY(srcgan_sum2x2_nhwc(dcur.p, dcur.cs, dst.p, dst.cs, in_act ? xin_k.p : nullptr, xin_k.cs, 0.2f, B, o.hin, o.win, nf, dt, st));
+            }
+            dcur = dst;
+        }
+        // unused parameters of the forward (upconv2 in mode x2): their gradient is zero here, None in the reference
+        for (int k = 0; k < P.nlw; ++k)
+            if (!seen[k]) {
+                if (G(P.p_lg[k])) SG_HIP(hipMemsetAsync(G(P.p_lg[k]), 0, (size_t)nf * nf * 9 * sizeof(float), (hipStream_t)st));
+                if (G(P.p_lg[k] + 1)) SG_HIP(hipMemsetAsync(G(P.p_lg[k] + 1), 0, (size_t)nf * sizeof(float), (hipStream_t)st));
+            }
+    } else {
     // conv_last
     TRef Ul = T_(P.U[P.nst], nf);
     if (G(P.p_last_w))
@@ -400,8 +505,11 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         if (s > 0) cv.mask(Us, 0);
         SG_TRY(cv.run(st));
     }
+    }
+    TRef dfea = dU0;
+    if (P.legacy != 2) {
     // U0 = fea + trunk_conv(T): d(trunk_conv out) = dU0, d(fea) += dU0 (joined at the end)
-    TRef dU0 = S_(Q.dU[0], nf), Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
+    TRef Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
     if (G(P.p_trunk_w))
         SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st, G(P.p_trunk_b)));
     else if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
@@ -458,7 +566,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     TRef trunk_in = Abuf(0);
     SG_TRY(srcgan_add_inplace_planes(dU0.p, dU0.cs, dU0.coff, dU0.plane, dcur.p, dcur.cs, dcur.coff, dcur.plane,
                                      P.ndn ? trunk_in.p : nullptr, trunk_in.cs, 0, trunk_in.plane, 0.2f, npix_t, nf, dt, st));
-    TRef dfea = dU0;             // (dU0 is not needed any more: the join is accumulated into it, NHWC)
+    }                            // (dU0 is not needed any more: the join is accumulated into it, NHWC)
     for (int s = P.ndn - 1; s >= 0; --s) {     // 3x3 s2 p1 stages of RDDBNetA, last to first
         const int hi = c->H >> s, wi = c->W >> s, ho = hi / 2, wo = wi / 2;
         TRef xin_s = s == 0 ? T_(P.fea0, nf) : T_(P.dn[s - 1], nf);

@@ -24,7 +24,8 @@ import torch.nn as nn
 
 from . import _native as N
 
-__all__ = ["RDDBNet", "RDDBNetA", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv", "get_deconv_params"]
+__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
+           "get_deconv_params"]
 
 
 def get_deconv_params(upscale_factor):
@@ -85,12 +86,13 @@ class _RddbFn(torch.autograd.Function):
     def forward(ctx, x, cfg_items, *params):
         N.require_cuda(x, "RDDBNet.forward")
         lib = N.lib()
-        in_ch, out_ch, up, nf, nb, gc, dtype, down = cfg_items
+        in_ch, out_ch, up, nf, nb, gc, dtype, down = cfg_items[:8]
+        legacy = cfg_items[8] if len(cfg_items) > 8 else 0
         if x.dim() != 4 or x.shape[1] != in_ch:
             raise ValueError(f"RDDBNet expects [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
         B, _, H, W = x.shape
-        cfg = N.RddbCfg(in_ch, out_ch, up, nf, nb, gc, B, H, W, dtype, down)
+        cfg = N.RddbCfg(in_ch, out_ch, up, nf, nb, gc, B, H, W, dtype, down, legacy)
         for p in params:
             N.require_cuda(p, "RDDBNet parameter")
         plist = [p.detach().contiguous() for p in params]
@@ -189,6 +191,80 @@ class RDDBNetA(RDDBNet):
         # native order: conv_first, down_layers, trunk, trunk_conv, conv_last
         ps = [self.conv_first.weight, self.conv_first.bias, *self.down_layers.parameters(),
               *self.RRDB_trunk.parameters(), self.trunk_conv.weight, self.trunk_conv.bias, self.conv_last.weight]
+        return _RddbFn.apply(x, cfg, *ps)
+
+
+class _LegacyRRDB(_HolderOnly):
+    """Holder for the RRDB of model/model.py:214-226: like rddb.py's, but its constructor already re-initialises its
+    own convolutions (kaiming-normal) -- kept so that a seeded construction consumes the RNG exactly like the reference."""
+
+    def __init__(self, nf, gc=32):
+        super().__init__()
+        for j in (1, 2, 3):
+            setattr(self, f"RDB{j}", ResidualDenseBlock_5(nf, gc))
+        _kaiming_like_reference(self)
+
+
+_MODES = {"x1": 1, "x2": 2, "x4": 4}
+
+
+class RDDBNetB(nn.Module):
+    """Legacy nearest-up-sampling generator, drop-in for reference ``model.model.RDDBNetB`` (model/model.py:394-440; G_A of
+    train.py:172,177).  ``RDDBNetB(in_nc, out_nc, nf, nb=3, gc=32, mode='x2')``; forward: conv_first -> RRDB trunk ->
+    trunk_conv + skip -> [nearest x2 -> upconv -> LeakyReLU] (x4: upconv1 then upconv2; x2: upconv1 twice, the second
+    without up-sampling) -> HRconv + LeakyReLU eight times -> conv_last (with bias).  Any other mode leaves the
+    resolution unchanged in the reference; only 'x2' / 'x4' are accepted here."""
+
+    _legacy = 1
+    _tail = ("upconv1", "upconv2", "HRconv")
+
+    def __init__(self, in_nc, out_nc, nf, nb=3, gc=32, mode="x2", dtype=None):
+        super().__init__()
+        if mode not in _MODES or (self._legacy == 1 and mode == "x1"):
+            raise NotImplementedError(f"{type(self).__name__}: mode {mode!r} is not supported")
+        self.conv_first = nn.Conv2d(in_nc, nf, 3, 1, 1, bias=True)
+        self.RRDB_trunk = nn.Sequential(*[_LegacyRRDB(nf=nf, gc=gc) for _ in range(nb)])
+        self.trunk_conv = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        for name in self._tail:
+            setattr(self, name, nn.Conv2d(nf, nf, 3, 1, 1, bias=True))
+        self.mode = mode
+        self.nb = nb
+        self.conv_last = nn.Conv2d(nf, out_nc, 3, 1, 1, bias=True)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        _kaiming_like_reference(self)
+        self._cfg = (in_nc, out_nc, _MODES[mode], nf, nb, gc)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, x):
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), 0, self._legacy)
+        ps = list(self.parameters())                            # state_dict order == native order
+        if self.mode == "x2":       # upconv2 is not on the x2 graph (model.py:430-432): its .grad stays None, as in the reference
+            skip = {id(self.upconv2.weight), id(self.upconv2.bias)}
+            ps = [p.detach() if id(p) in skip else p for p in ps]
+        return _RddbFn.apply(x, cfg, *ps)
+
+    def extra_repr(self):
+        return f"native gfx950, mode={self.mode}, compute_dtype={self.compute_dtype}"
+
+
+class LegacyRDDBNet(RDDBNetB):
+    """Drop-in for the *legacy* ``model.model.RDDBNet`` (model/model.py:347-391; not the rddb.py class that
+    ``from model import *`` exports): ``(in_nc, out_nc, nf, nb, gc=32, mode='x2')``.  Its forward computes the RRDB trunk
+    and discards it (model.py:382-383), so the output is conv_first -> [nearest x2 -> upconv -> LeakyReLU] per x2 stage
+    (mode 'x1': upconv without up-sampling) -> HRconv + LeakyReLU twice -> conv_last; the trunk parameters exist in the
+    state_dict and receive no gradient (``.grad`` stays None, as in the reference)."""
+
+    _legacy = 2
+    _tail = ("upconv", "HRconv")
+
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32, mode="x2", dtype=None):
+        super().__init__(in_nc, out_nc, nf, nb=nb, gc=gc, mode=mode, dtype=dtype)
+
+    def forward(self, x):
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), 0, self._legacy)
+        # the trunk is not on the graph: pass its parameters detached so autograd leaves their .grad at None
+        trunk = {id(p) for p in self.RRDB_trunk.parameters()} | {id(self.trunk_conv.weight), id(self.trunk_conv.bias)}
+        ps = [p.detach() if id(p) in trunk else p for p in self.parameters()]
         return _RddbFn.apply(x, cfg, *ps)
 
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import ops
 from .losses import GANLoss, L1Loss, PSNRLoss
-from .model import NLayerDiscriminator, RDDBNet, RDDBNetA
+from .model import NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB
 
 __all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasParams", "set_requires_grad"]
 
@@ -124,6 +124,9 @@ class CycleParams:
         self.net = "1"
         self.nf, self.nb, self.gc, self.ndf, self.n_layers = 64, 3, 32, 64, 2
         self.dtype = None
+        # G_A class: "RDDBNetB" is what reference train.py:172,177 constructs (legacy nearest-up-sampling generator,
+        # model/model.py:394); "RDDBNet" (rddb.py, deconv up-sampler) is the generator BASELINE.json's configs name.
+        self.G_A = "RDDBNet"
 
 
 class SRCycleGAN:
@@ -135,7 +138,10 @@ class SRCycleGAN:
         up = 2 if opt.mode == "x2" else 4
         self.up = up
         dev = opt.device
-        self.netG_A = RDDBNet(3, 3, up, nf=opt.nf, nb=opt.nb, gc=opt.gc, dtype=opt.dtype).to(dev)
+        if getattr(opt, "G_A", "RDDBNet") == "RDDBNetB":
+            self.netG_A = RDDBNetB(3, 3, opt.nf, nb=opt.nb, gc=opt.gc, mode=opt.mode, dtype=opt.dtype).to(dev)
+        else:
+            self.netG_A = RDDBNet(3, 3, up, nf=opt.nf, nb=opt.nb, gc=opt.gc, dtype=opt.dtype).to(dev)
         self.netG_B = RDDBNetA(3, 3, up, nf=opt.nf, nb=opt.nb, gc=opt.gc, dtype=opt.dtype).to(dev)
         self.netD_A = NLayerDiscriminator(3, opt.ndf, opt.n_layers, dtype=opt.dtype).to(dev)
         self.netD_B = NLayerDiscriminator(3, opt.ndf, opt.n_layers, dtype=opt.dtype).to(dev)

@@ -87,3 +87,33 @@ def test_paired_step_is_deterministic():
             m.optimize_parameters(x, y)
         outs.append(torch.cat([p.detach().reshape(-1) for p in list(m.netG.parameters()) + list(m.netD.parameters())]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_cycle_step_with_reference_g_a_vs_oracle():
+    """The cycle step with G_A = RDDBNetB, the generator reference train.py:172,177 actually constructs (legacy
+    nearest-up-sampling generator, model/model.py:394-440; golden-pinned), G_B = the build-defined RDDBNetA."""
+    from srcgan_amd import train as T
+    opt = T.CycleParams(device="cuda")
+    opt.nf, opt.nb, opt.gc, opt.ndf, opt.n_layers, opt.dtype, opt.G_A = 16, 1, 8, 16, 3, "fp32", "RDDBNetB"
+    torch.manual_seed(11)
+    m = T.SRCycleGAN(opt)
+    base = oracle.make_cycle_state(up=2, nf=16, nb=1, gc=8, ndf=16, n_layers=3, seed=9)
+    ga = {k: v.detach().cpu().clone() for k, v in m.netG_A.state_dict().items()}
+    st = oracle.CycleState(ga, {k: v.detach() for k, v in base.gb.items()}, {k: v.detach() for k, v in base.da.items()},
+                           {k: v.detach() for k, v in base.db.items()}, 2, seed=9, ga_kind="rddbnetb")
+    m.netG_B.load_state_dict(st.gb); m.netD_A.load_state_dict(st.da); m.netD_B.load_state_dict(st.db)
+    rng_a, rng_b = random.Random(5), random.Random(5)
+    m.fake_A_pool.rng = m.fake_B_pool.rng = rng_a
+    st.pool_a.rng = st.pool_b.rng = rng_b
+    torch.manual_seed(3)
+    for step in range(2):
+        a, b = torch.rand(2, 3, 24, 32), torch.rand(2, 3, 48, 64)
+        ref = oracle.cycle_step(st, a, b)
+        m.optimize_parameters(a.cuda(), b.cuda())
+        mine = {"loss_G": m.loss_G, "loss_D_A": m.loss_D_A, "loss_D_B": m.loss_D_B,
+                "loss_cycle": m.loss_cycle_A + m.loss_cycle_B, "loss_iden": m.loss_iden_A + m.loss_iden_B,
+                "loss_G_GAN": m.loss_G_A + m.loss_G_B}
+        for k, v in ref.items():
+            assert abs(float(mine[k]) - v) < 1e-3 * max(1.0, abs(v)), (step, k, float(mine[k]), v)
+    for k, v in m.netG_A.state_dict().items():
+        assert rel_err(v.cpu(), st.ga[k].detach()) < 2e-3, k

@@ -196,3 +196,51 @@ def test_cpu_tensor_fails_loudly():
     net = RDDBNet(3, 3, 2, nf=16, nb=1, gc=8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.rand(1, 3, 8, 8))
+
+
+@pytest.mark.parametrize("tag,kind", [("rddbnetb_x2", "B"), ("rddbnetb_x4", "B"), ("legacy_rddbnet_x1", "L"),
+                                      ("legacy_rddbnet_x2", "L"), ("legacy_rddbnet_x4", "L")])
+def test_legacy_generators_golden_f32(tag, kind):
+    """Legacy nearest-up-sampling generators (reference model/model.py:347-440; RDDBNetB = G_A of train.py:172) against
+    reference outputs, input gradients and parameter gradients (shared HRconv / upconv weights accumulate)."""
+    from srcgan_amd import RDDBNetB, LegacyRDDBNet, L1Loss
+    g = load_golden(tag)
+    ic, oc, nf, nb, gc, up = [int(v) for v in g["cfg"]]
+    cls = RDDBNetB if kind == "B" else LegacyRDDBNet
+    net = _load(cls(ic, oc, nf, nb, gc, f"x{up}", dtype="fp32"), sub(g, "sd/"))
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.cpu(), g["y"]) < F32_TOL
+    loss = L1Loss()(y, torch.from_numpy(g["t"]).cuda())
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < F32_TOL
+    grads, nograd = sub(g, "grad/"), {str(k) for k in g["nograd"]}
+    for k, p in net.named_parameters():
+        if k in nograd:
+            assert p.grad is None, k          # unused by the reference's forward: .grad stays None there too
+        else:
+            assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+
+
+@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 5e-2)])
+def test_rddbnetb_full_width_vs_oracle(dt, tol):
+    """RDDBNetB at nf=64, gc=32, x4 on an odd-sized input, f32 and bf16, against the (golden-pinned) oracle restatement."""
+    from srcgan_amd import RDDBNetB, L1Loss
+    torch.manual_seed(5)
+    net = RDDBNetB(3, 3, 64, nb=1, gc=32, mode="x4", dtype=dt).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(1, 3, 13, 21)
+    t = torch.rand(1, 3, 52, 84)
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = oracle.rddbnetb_forward(ref_sd, xr, "x4")
+    oracle.l1_loss(yr, t).backward()
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    L1Loss()(y, t.cuda()).backward()
+    err = rel_err if dt == "fp32" else rel_l2
+    assert err(y.cpu(), yr) < tol
+    assert err(xg.grad.cpu(), xr.grad) < tol * 2
+    worst = max(err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+    assert worst < tol * 2, worst

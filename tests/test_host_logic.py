@@ -137,3 +137,25 @@ def test_dtype_selection():
     assert srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8, dtype="bf16").compute_dtype == "bf16"
     with pytest.raises(ValueError):
         srcgan_amd.RDDBNet(3, 3, 2, nf=16, nb=1, gc=8, dtype="fp8")
+
+
+@pytest.mark.parametrize("tag,kind", [("rddbnetb_x2", "B"), ("rddbnetb_x4", "B"), ("legacy_rddbnet_x2", "L")])
+def test_legacy_generators_state_dict_and_seeded_init(tag, kind):
+    """RDDBNetB / legacy RDDBNet (reference model/model.py:347-440): reference state_dict keys, shapes and -- modules being
+    created and re-initialised in the reference's order -- bit-identical seeded initial weights."""
+    g = load_golden(tag)
+    ic, oc, nf, nb, gc, up = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    cls = srcgan_amd.RDDBNetB if kind == "B" else srcgan_amd.LegacyRDDBNet
+    torch.manual_seed(0)
+    net = cls(ic, oc, nf, nb, gc, f"x{up}")
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert [n for n, _ in net.named_parameters()] == oracle.legacy_keys(nb, ("upconv1", "upconv2", "HRconv") if kind == "B" else ("upconv", "HRconv"))
+    for k, v in ref.items():
+        assert torch.equal(sd[k], v), k
+    net.load_state_dict(ref, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.rand(1, ic, 8, 8))
+    with pytest.raises(NotImplementedError):
+        srcgan_amd.RDDBNetB(3, 3, 16, 1, 8, "x8")

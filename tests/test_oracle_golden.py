@@ -162,3 +162,31 @@ def test_cycle_step_runs():
     out2 = oracle.cycle_step(st, a, b)
     assert all(np.isfinite(v) for v in out1.values())
     assert out2["loss_cycle"] < out1["loss_cycle"] * 1.5
+
+
+LEGACY = [("rddbnetb_x2", "B"), ("rddbnetb_x4", "B"), ("legacy_rddbnet_x1", "L"), ("legacy_rddbnet_x2", "L"), ("legacy_rddbnet_x4", "L")]
+
+
+@pytest.mark.parametrize("tag,kind", LEGACY)
+def test_legacy_generators(tag, kind):
+    """model/model.py:347-440 (legacy RDDBNet, RDDBNetB = G_A of the cycle) against reference outputs and gradients."""
+    g = load_golden(tag)
+    ic, oc, nf, nb, gc, up = [int(v) for v in g["cfg"]]
+    mode = f"x{up}"
+    sd = _req(sub(g, "sd/"))
+    tail = ("upconv1", "upconv2", "HRconv") if kind == "B" else ("upconv", "HRconv")
+    assert list(sd.keys()) == oracle.legacy_keys(nb, tail)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = (oracle.rddbnetb_forward if kind == "B" else oracle.legacy_rddbnet_forward)(sd, x, mode)
+    loss = oracle.l1_loss(y, torch.from_numpy(g["t"]))
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert rel_err(x.grad, g["dx"]) < TOL
+    grads = sub(g, "grad/")
+    for k, v in grads.items():
+        assert rel_err(sd[k].grad, v) < TOL, k
+    # parameters the reference's forward never touches get no gradient there, and none here
+    for k in g["nograd"]:
+        assert sd[str(k)].grad is None, k
+    assert set(grads) | {str(k) for k in g["nograd"]} == set(sd)
