@@ -181,6 +181,18 @@ int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const
                               const void* mz, int mz_cs, int mz_coff, long mz_plane, float mslope, long npix, int C,
                               int dtype, void* stream);
 
+/* GroupNorm (+ residual add + ReLU) on NHWC activations (resdeconv.py:61-97,118-121; nn.GroupNorm(G, C), affine, biased
+ * variance): y = relu?((x - mean[b][g]) * rstd[b][g] * gamma[c] + beta[c] [+ res]).  stats: device f32 [B][G][2] = {mean, rstd}
+ * (written by forward, read by backward).  backward: g = dy [* (yact > 0)] (yact = the forward output when ReLU was applied);
+ * dx = GroupNorm backward of g; dres (optional) = g (gradient of the residual branch); dgamma / dbeta (optional) f32 [C].
+ * scratch: srcgan_gn_scratch_floats(B, C) floats.  C/epp must divide 256 (epp = 16 bytes of channels). */
+size_t srcgan_gn_scratch_floats(int B, int C);
+int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void* y, int y_cs, const float* gamma, const float* beta,
+                      float* stats, int B, long hw, int C, int G, float eps, int relu, int dtype, float* scratch, void* stream);
+int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
+                       void* dx, int dx_cs, void* dres, int dres_cs, float* dgamma, float* dbeta, int accumulate,
+                       int B, long hw, int C, int G, int dtype, float* scratch, void* stream);
+
 /* x2 nearest up-sampling of an NHWC feature map (src may be a channel slice of a blocked buffer: s_plane != 0) and its
  * adjoint: dst[y][x] = sum of the 2x2 block of src, times LeakyReLU'(mz[y][x]) when mz is given.  Replaces
  * F.interpolate(scale_factor=2, mode='nearest') and its backward in the legacy generators (model/model.py:384-386,428-433). */

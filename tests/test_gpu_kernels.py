@@ -354,3 +354,56 @@ def test_wgrad_dense_production_tiles(ops, blocked, hw):
     for (g0, g1, gw, gb, cin, alpha), (rw, rb) in zip(segs, refs):
         assert rel_err(gw.cpu(), rw) < TOL[dt], (g0, cin)
         assert rel_err(gb.cpu(), rb) < TOL[dt], (g0, cin)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ResDeconv colouriser building blocks (reference src/model/resdeconv.py): GroupNorm(32) + residual + ReLU, 7x7 s2 stem,
+# 1x1 s2 shortcut convolution, and their weight gradients.
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,hw,relu,res", [(64, (9, 14), True, False), (128, (8, 8), True, True), (512, (4, 6), False, False), (256, (16, 16), True, True)])
+def test_group_norm_fwd_bwd(ops, dt, C, hw, relu, res):
+    torch.manual_seed(31)
+    H, W = hw
+    x = _q(torch.randn(2, C, H, W), dt).requires_grad_(True)
+    r = _q(torch.randn(2, C, H, W), dt).requires_grad_(True)
+    gamma = (torch.rand(C) + 0.5).requires_grad_(True)
+    beta = (torch.rand(C) - 0.5).requires_grad_(True)
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = _q(torch.randn_like(y), dt)
+    y.backward(dy)
+    xg, rg = _nhwc(ops, x.detach(), C, dt), _nhwc(ops, r.detach(), C, dt)
+    yg, stats = ops.group_norm(xg, gamma.detach().cuda(), beta.detach().cuda(), 32, res=rg if res else None, relu=relu)
+    assert rel_err(ops.to_nchw(yg).cpu(), y.detach()) < TOL[dt]
+    dx, dres, dgm, dbt = ops.group_norm_bwd(_nhwc(ops, dy, C, dt), xg, gamma.detach().cuda(), stats, 32, yact=yg if relu else None, want_dres=res)
+    assert rel_err(ops.to_nchw(dx).cpu(), x.grad) < TOL[dt] * 2
+    if res:
+        assert rel_err(ops.to_nchw(dres).cpu(), r.grad) < TOL[dt]
+    assert rel_err(dgm.cpu(), gamma.grad) < TOL[dt] * 2
+    assert rel_err(dbt.cpu(), beta.grad) < TOL[dt] * 2
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,s,pad,cin,cout,hw", [(7, 2, 3, 3, 64, (32, 44)), (7, 2, 3, 3, 64, (17, 9)), (1, 2, 0, 64, 128, (16, 24)), (1, 2, 0, 256, 512, (9, 7))])
+def test_stem_and_shortcut_convs(ops, dt, k, s, pad, cin, cout, hw):
+    torch.manual_seed(32)
+    H, W = hw
+    x = _q(torch.rand(2, cin, H, W) - 0.5, dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, k, k) * 0.1, dt).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    dy = _q(torch.rand_like(y) - 0.5, dt)
+    y.backward(dy)
+    OH, OW = y.shape[2:]
+    cs = max(8, cin)
+    xg = _nhwc(ops, x.detach(), cs, dt)
+    yg = torch.zeros(2, OH, OW, cout, device="cuda", dtype=xg.dtype)
+    wp = ops.pack_weight(w.detach().cuda(), cout, cin, k, k, cin * k * k, k * k, k, 1, 0, dt)
+    ops.conv_igemm(xg, wp, yg, kh=k, kw=k, stride=s, Cin=cs, Cout=cout, pad=(pad, pad))      # image channels are zero-padded to 8
+    assert rel_err(ops.to_nchw(yg).cpu(), y.detach()) < TOL[dt]
+    gw = torch.zeros(cout, cin, k, k, device="cuda")
+    ops.conv_wgrad(_nhwc(ops, dy, cout, dt), xg, gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(pad, pad), layout=(cin * k * k, k * k, k, 1, 0))
+    assert rel_err(gw.cpu(), w.grad) < TOL[dt]
