@@ -268,6 +268,22 @@ int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, con
 int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
                             void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
 
+/* ResDeconv colouriser (resdeconv.py:99-195; C network of trainCas.py:31,99-100): [B,3,H,W] f32 NCHW -> [B,tar_ch,H,W];
+ * H, W multiples of 16.  params/grads in state_dict order (conv1.weight, bn1.{weight,bias}, layer1.0.conv1.weight, ...,
+ * pred.weight); a null grads[i] skips that gradient.  No gradient w.r.t. the input (it is data in every harness). */
+typedef struct srcgan_resdeconv_cfg {
+    int in_ch, out_ch;     /* in_ch must be 3 (a 1-channel source is replicated by the caller, resdeconv.py:166-167) */
+    int B, H, W;
+    int dtype;
+} srcgan_resdeconv_cfg;
+int srcgan_resdeconv_num_params(const srcgan_resdeconv_cfg* c);
+size_t srcgan_resdeconv_ws_bytes(const srcgan_resdeconv_cfg* c);
+size_t srcgan_resdeconv_bwd_scratch_bytes(const srcgan_resdeconv_cfg* c);
+int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw, const float* const* params, void* ws,
+                             float* y_nchw, void* stream);
+int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws,
+                              void* scratch, float* const* grads, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Launch profiling for bench.py: when enabled, every conv_igemm / conv_wgrad launch is bracketed by
  * HIP events on its launch stream.  collect() synchronises, aggregates per kernel class

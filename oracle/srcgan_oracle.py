@@ -32,7 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
-    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward",
 ]
 
 
@@ -131,6 +131,38 @@ def legacy_keys(nb: int, tail) -> List[str]:
     for t in tail:
         keys += [t + ".weight", t + ".bias"]
     return keys + ["conv_last.weight", "conv_last.bias"]
+
+
+# ---------------------------------------------------------------------------
+# Colouriser: ResDeconv  (reference src/model/resdeconv.py:56-195, BN='GN', layers=[2,2,2,2])
+# ---------------------------------------------------------------------------
+
+def _rd_block(sd: State, pre: str, x: Tensor, stride: int) -> Tensor:
+    """BasicBlock.forward, resdeconv.py:78-97 (GroupNorm(32), ReLU; 1x1 strided conv + GroupNorm shortcut when present)."""
+    gn = lambda t, n: F.group_norm(t, 32, sd[pre + n + ".weight"], sd[pre + n + ".bias"], 1e-5)
+    out = F.relu(gn(F.conv2d(x, sd[pre + "conv1.weight"], None, stride, 1), "bn1"))
+    out = gn(F.conv2d(out, sd[pre + "conv2.weight"], None, 1, 1), "bn2")
+    idn = x
+    if pre + "downsample.0.weight" in sd:
+        idn = F.group_norm(F.conv2d(x, sd[pre + "downsample.0.weight"], None, stride, 0), 32,
+                           sd[pre + "downsample.1.weight"], sd[pre + "downsample.1.bias"], 1e-5)
+    return F.relu(out + idn)
+
+
+def resdeconv_forward(sd: State, x: Tensor) -> Tensor:
+    """ResDeconv.forward, resdeconv.py:164-195.  A 1-channel source is replicated to the stem's 3 channels."""
+    if x.shape[1] == 1:
+        x = torch.cat([x, x, x], dim=1)
+    t = F.relu(F.group_norm(F.conv2d(x, sd["conv1.weight"], None, 2, 3), 32, sd["bn1.weight"], sd["bn1.bias"], 1e-5))
+    for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2), ("layer4", 2)):
+        t = _rd_block(sd, f"{name}.0.", t, stride)
+        t = _rd_block(sd, f"{name}.1.", t, 1)
+    for dc, name in (("deconv10", "upRes1"), ("deconv11", "upRes2"), ("deconv12", "upRes3")):
+        t = F.conv_transpose2d(t, sd[dc + ".weight"], None, 2, 0)
+        t = _rd_block(sd, f"{name}.0.", t, 1)
+        t = _rd_block(sd, f"{name}.1.", t, 1)
+    t = F.conv_transpose2d(t, sd["deconv13.weight"], None, 2, 0)
+    return F.conv2d(t, sd["pred.weight"], None, 1, 1)
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:

@@ -84,6 +84,10 @@ class RddbCfg(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("down", C.c_int), ("legacy", C.c_int)]
 
 
+class ResDeconvCfg(C.Structure):
+    _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+
+
 class NLayerDCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("ndf", C.c_int), ("n_layers", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
@@ -127,6 +131,11 @@ SIGNATURES = {
     "srcgan_rgb_to_gray": (_I, [_P, _P, _I, _I, _I, _P]),
     "srcgan_bilinear_down": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "srcgan_nearest_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "srcgan_resdeconv_num_params": (_I, [C.POINTER(ResDeconvCfg)]),
+    "srcgan_resdeconv_ws_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
+    "srcgan_resdeconv_bwd_scratch_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
+    "srcgan_resdeconv_forward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P]),
+    "srcgan_resdeconv_backward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P, _P]),
     "srcgan_prof_enable": (_I, [_I]),
     "srcgan_prof_collect": (_I, []),
     "srcgan_prof_get": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

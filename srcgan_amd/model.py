@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _native as N
 
-__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
+__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
            "get_deconv_params"]
 
 
@@ -266,6 +266,124 @@ class LegacyRDDBNet(RDDBNetB):
         trunk = {id(p) for p in self.RRDB_trunk.parameters()} | {id(self.trunk_conv.weight), id(self.trunk_conv.bias)}
         ps = [p.detach() if id(p) in trunk else p for p in self.parameters()]
         return _RddbFn.apply(x, cfg, *ps)
+
+
+# ------------------------------------------------------------------------------------------------ ResDeconv colouriser
+class _ResDeconvFn(torch.autograd.Function):
+    """One native forward / one native backward for the whole colouriser (resdeconv.py:164-195)."""
+
+    @staticmethod
+    def forward(ctx, x, out_ch, dtype, *params):
+        N.require_cuda(x, "ResDeconv.forward")
+        lib = N.lib()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"ResDeconv's stem expects 3 channels, got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, _, H, W = x.shape
+        if H % 16 or W % 16:
+            raise ValueError(f"ResDeconv needs H and W to be multiples of 16 (four stride-2 stages), got {H}x{W}")
+        cfg = N.ResDeconvCfg(3, out_ch, B, H, W, dtype)
+        for p in params:
+            N.require_cuda(p, "ResDeconv parameter")
+        plist = [p.detach().contiguous() for p in params]
+        ws = N.workspace(lib.srcgan_resdeconv_ws_bytes(C.byref(cfg)), x.device)
+        y = torch.empty(B, out_ch, H, W, dtype=torch.float32, device=x.device)
+        N.check(lib.srcgan_resdeconv_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(),
+                                             N.stream_ptr(x.device)), "srcgan_resdeconv_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(*plist)
+        ctx.hook = _grad_hooks.get("resdeconv")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = N.lib()
+        params = list(ctx.saved_tensors)
+        cfg = ctx.cfg
+        if ctx.ws is None:
+            raise RuntimeError("ResDeconv backward called twice (activations were released)")
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("ResDeconv: no gradient w.r.t. the input (detach it: the reference harness feeds it data, trainCas.py:99-100,108)")
+        dy = dy.contiguous().float()
+        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(params)]
+        scratch = N.workspace(lib.srcgan_resdeconv_bwd_scratch_bytes(C.byref(cfg)), dy.device)
+        N.check(lib.srcgan_resdeconv_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
+                                              N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_resdeconv_backward")
+        ctx.ws = None
+        if ctx.hook is not None:
+            ctx.hook(grads)
+        return (None, None, None, *grads)
+
+
+class _BasicBlockHolder(_HolderOnly):
+    """Parameter holder of resdeconv.py:56-76 BasicBlock (attribute order = the reference's state_dict order)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.GroupNorm(32, planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.GroupNorm(32, planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResDeconv(nn.Module):
+    """Colouriser, drop-in for reference ``model.ResDeconv`` (src/model/resdeconv.py:99-195, BN='GN', layers=[2,2,2,2]):
+    ``ResDeconv(src_ch=1, tar_ch=3)``; ``forward(x[B,src_ch,H,W]) -> [B,tar_ch,H,W]`` (H, W multiples of 16).
+    A 1-channel source is replicated to 3 channels like the reference (resdeconv.py:166-167)."""
+
+    def __init__(self, src_ch=1, tar_ch=3, layers=(2, 2, 2, 2), dtype=None):
+        super().__init__()
+        if list(layers) != [2, 2, 2, 2]:
+            raise NotImplementedError("native ResDeconv implements the reference default layers=[2, 2, 2, 2]")
+        self.src_ch = src_ch
+        if isinstance(tar_ch, list):
+            tar_ch = sum(tar_ch)
+        self.tar_ch = tar_ch
+        self.inplanes = 64
+        # creation order == the reference's (it fixes which random numbers each default initialisation consumes)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.GroupNorm(32, 64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = self._make_layer(64, 2, 1)
+        self.layer2 = self._make_layer(128, 2, 2)
+        self.layer3 = self._make_layer(256, 2, 2)
+        self.layer4 = self._make_layer(512, 2, 2)
+        self.deconv10 = nn.ConvTranspose2d(512, 256, 2, 2, 0, bias=False)
+        self.inplanes = 256
+        self.upRes1 = self._make_layer(256, 2, 1)
+        self.deconv11 = nn.ConvTranspose2d(256, 128, 2, 2, 0, bias=False)
+        self.inplanes = 128
+        self.upRes2 = self._make_layer(128, 2, 1)
+        self.deconv12 = nn.ConvTranspose2d(128, 64, 2, 2, 0, bias=False)
+        self.inplanes = 64
+        self.upRes3 = self._make_layer(64, 2, 1)
+        self.deconv13 = nn.ConvTranspose2d(64, 64, 2, 2, 0, bias=False)
+        self.pred = nn.Conv2d(64, tar_ch, kernel_size=3, stride=1, padding=1, bias=False)
+        _kaiming_like_reference(self)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        norm = nn.GroupNorm(32, planes)
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False), norm)
+        layers = [_BasicBlockHolder(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(_BasicBlockHolder(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        if self.src_ch == 1:
+            x = torch.cat([x, x, x], dim=1)
+        return _ResDeconvFn.apply(x, self.tar_ch, N.dtype_id(self.compute_dtype), *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
 
 
 class _NLayerDFn(torch.autograd.Function):
