@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import ops
 from .losses import GANLoss, L1Loss, PSNRLoss
-from .model import NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB
+from .model import NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
 
 __all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasParams", "set_requires_grad"]
 
@@ -217,7 +217,7 @@ class SRCycleGAN:
 class CasParams:
     """trainCas.py:156-164 defaults + the three argparse flags (:168-177)."""
 
-    def __init__(self, device="cuda", SRModel="RDDBNet", CModel="RDDBNet", up=2):
+    def __init__(self, device="cuda", SRModel="RDDBNet", CModel="ResDeconv", up=2):
         self.device = torch.device(device)
         self.lr = 1e-4
         self.batch_size = 1
@@ -229,14 +229,13 @@ class CasParams:
 
 
 # name -> constructor(in_ch, out_ch, up) ; the reference resolves these with eval() (trainCas.py:30-31)
-MODEL_REGISTRY = {"RDDBNet": RDDBNet}
+MODEL_REGISTRY = {"RDDBNet": RDDBNet, "ResDeconv": ResDeconv}
 
 
 class CasSRC:
     """Cascade SR + colourisation step (reference src/trainCas.py:18-153).  ``netG_A2C`` (SR on the gray
-    image) is the native RDDBNet; ``netG_C2B`` defaults to a size-preserving native RDDBNet(1,3,up=1)
-    (the reference default ResDeconv is SURVEY.md section 8f "next" row #1) and can be any nn.Module class
-    registered in MODEL_REGISTRY."""
+    image) is the native RDDBNet; ``netG_C2B`` is the native ResDeconv colouriser (the reference's default
+    ``--CModel``, trainCas.py:170); both resolve through MODEL_REGISTRY like the reference's ``eval(opt.*Model)``."""
 
     def __init__(self, opt: CasParams):
         self.opt = opt

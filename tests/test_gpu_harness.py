@@ -44,6 +44,29 @@ def test_cas_step_sr_half_golden():
     assert set(means) == {"loss_SR", "psnr_SR", "loss_C", "psnr_C"}
 
 
+def test_cas_step_full_golden():
+    """The whole CasSRC.optimize_parameters of the reference (trainCas.py:133-153) with its default colouriser: both
+    networks are constructed under the reference's seed in the reference's order, so the native ResDeconv starts from
+    the reference's weights and loss_C / psnr_C of the golden step must be reproduced too."""
+    from srcgan_amd import train as T, RDDBNet
+    g = load_golden("cas_step")
+    T.MODEL_REGISTRY["RDDBNetTiny"] = lambda i, o, up: RDDBNet(i, o, up, nf=16, nb=1, gc=8, dtype="fp32")
+    opt = T.CasParams(device="cuda", SRModel="RDDBNetTiny", CModel="ResDeconv", up=2)
+    opt.dtype = "fp32"
+    torch.manual_seed(0)                      # make_golden.py: torch.manual_seed(0); trainCas.CasSRC(Opt)
+    m = T.CasSRC(opt)
+    for k, v in sub(g, "sr0/").items():       # same seed, same construction order -> the reference's initial SR weights
+        assert torch.equal(m.netG_A2C.state_dict()[k].cpu(), v), k
+    m.update_lr(opt)
+    realA, realB = torch.from_numpy(g["realA"]).cuda(), torch.from_numpy(g["realB"]).cuda()
+    m.optimize_parameters(realA, realB)
+    assert abs(float(m.loss_SR) - float(g["loss_SR"])) < 1e-5
+    assert abs(float(m.loss_C) - float(g["loss_C"])) < 1e-5
+    assert abs(float(m.psnr_SR) - float(g["psnr_SR"])) < 1e-3
+    assert abs(float(m.psnr_C) - float(g["psnr_C"])) < 1e-3
+    assert m.fake_AB.shape == (1, 3, 64, 64)
+
+
 def test_cycle_step_vs_oracle():
     """Full cycle step (reference train.py:228-340: 3 passes per generator, frozen-D generator step, image pools,
     two discriminator backward passes) against the oracle restatement from identical weights.  G_B (RDDBNetA) is

@@ -159,3 +159,19 @@ def test_legacy_generators_state_dict_and_seeded_init(tag, kind):
         net(torch.rand(1, ic, 8, 8))
     with pytest.raises(NotImplementedError):
         srcgan_amd.RDDBNetB(3, 3, 16, 1, 8, "x8")
+
+
+def test_resdeconv_holder():
+    """ResDeconv colouriser: reference parameter count / state_dict layout, no CPU fallback, argument checks."""
+    net = srcgan_amd.ResDeconv(1, 3)
+    assert sum(p.numel() for p in net.parameters()) == 14982912 and len(list(net.parameters())) == 101
+    ks = list(net.state_dict().keys())
+    assert ks[:3] == ["conv1.weight", "bn1.weight", "bn1.bias"] and ks[-1] == "pred.weight"
+    assert "layer2.0.downsample.1.bias" in ks and "layer1.0.downsample.0.weight" not in ks
+    assert tuple(net.deconv10.weight.shape) == (512, 256, 2, 2) and tuple(net.conv1.weight.shape) == (64, 3, 7, 7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.rand(1, 1, 32, 32))
+    with pytest.raises(NotImplementedError):
+        srcgan_amd.ResDeconv(1, 3, layers=(3, 4, 6, 3))
+    from srcgan_amd import train as T
+    assert T.CasParams().CModel == "ResDeconv" and T.MODEL_REGISTRY["ResDeconv"] is srcgan_amd.ResDeconv
