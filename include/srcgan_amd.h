@@ -284,6 +284,14 @@ int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw,
 int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws,
                               void* scratch, float* const* grads, void* stream);
 
+/* Fused multi-tensor Adam (torch.optim.Adam.step() of trainCas.py:38-41,143-150 / train.py:191-192,331-340; torch's
+ * single-tensor arithmetic, default flags: no weight decay, no amsgrad).  tensors_dev: device array of records
+ * {float* p; const float* g; float* m; float* v;} (32 bytes); chunks_dev: device array of nchunks records
+ * {int tensor; int off; int n; int pad;} (16 bytes; off a multiple of 4, n <= 4096).  `step` = the 1-based step count of
+ * every tensor in the launch. */
+int srcgan_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, double lr, double beta1, double beta2, double eps,
+                     long step, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Launch profiling for bench.py: when enabled, every conv_igemm / conv_wgrad launch is bracketed by
  * HIP events on its launch stream.  collect() synchronises, aggregates per kernel class

@@ -136,6 +136,7 @@ SIGNATURES = {
     "srcgan_resdeconv_bwd_scratch_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_forward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P]),
     "srcgan_resdeconv_backward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P, _P]),
+    "srcgan_adam_step": (_I, [_P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _L, _P]),
     "srcgan_prof_enable": (_I, [_I]),
     "srcgan_prof_collect": (_I, []),
     "srcgan_prof_get": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

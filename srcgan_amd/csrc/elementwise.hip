@@ -756,3 +756,55 @@ extern "C" int srcgan_nearest_resize(const float* src, float* dst, int B, int C,
     SG_LAUNCH_CHECK();
     return 0;
 }
+
+// --------------------------------------------------------------------------- fused multi-tensor Adam
+// One launch updates every parameter of an optimiser group (697 tensors for the 23-block generator): replaces the
+// foreach kernels behind torch.optim.Adam.step() (reference trainCas.py:38-41,143-150; train.py:191-192,331-340) with the
+// arithmetic of torch's single-tensor path:  m += (g - m)(1 - b1)  [lerp];  v = b2 v + (1 - b2) g g;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  State tensors stay torch's (exp_avg, exp_avg_sq, step).
+struct SgAdamTensor { float* p; const float* g; float* m; float* v; };
+struct SgAdamChunk { int tensor, off, n, pad; };
+__global__ __launch_bounds__(256) void adam_multi_k(const SgAdamTensor* __restrict__ tensors, const SgAdamChunk* __restrict__ chunks,
+                                                    float w1, float b2, float omb2, float step_size, float inv_bc2_sqrt, float eps) {
+    const SgAdamChunk ck = chunks[blockIdx.x];
+    const SgAdamTensor t = tensors[ck.tensor];
+    float* cp = t.p + ck.off; const float* cg = t.g + ck.off; float* cm = t.m + ck.off; float* cv = t.v + ck.off;
+    for (int i = threadIdx.x * 4; i < ck.n; i += 1024) {
+        if (i + 4 <= ck.n) {
+            f32x4 p = *(f32x4*)(cp + i), m = *(f32x4*)(cm + i), v = *(f32x4*)(cv + i);
+            const f32x4 g = *(const f32x4*)(cg + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // torch.lerp: weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+                m[j] = w1 < 0.5f ? m[j] + w1 * (g[j] - m[j]) : g[j] - (g[j] - m[j]) * (1.f - w1);
+                v[j] = v[j] * b2 + omb2 * g[j] * g[j];
+                p[j] = p[j] - step_size * (m[j] / (sqrtf(v[j]) * inv_bc2_sqrt + eps));
+            }
+            *(f32x4*)(cp + i) = p; *(f32x4*)(cm + i) = m; *(f32x4*)(cv + i) = v;
+        } else {
+            for (int j = i; j < ck.n; ++j) {
+                const float g = cg[j];
+                float m = cm[j], v = cv[j];
+                m = w1 < 0.5f ? m + w1 * (g - m) : g - (g - m) * (1.f - w1);
+                v = v * b2 + omb2 * g * g;
+                cp[j] = cp[j] - step_size * (m / (sqrtf(v) * inv_bc2_sqrt + eps));
+                cm[j] = m; cv[j] = v;
+            }
+        }
+    }
+}
+// tensors_dev: ntensors records {p, g, m, v} (device f32 pointers, 16-byte aligned); chunks_dev: nchunks records
+// {tensor index, element offset (multiple of 4), count <= 4096, 0}.  The chunk table depends only on the shapes; the tensor
+// table is refreshed by the caller (srcgan_amd/optim.py) whenever a pointer (typically a fresh .grad) changes.
+extern "C" int srcgan_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, double lr, double beta1, double beta2, double eps,
+                                long step, void* stream) {
+    SG_REQUIRE(tensors_dev && chunks_dev && nchunks > 0 && step >= 1, "srcgan_adam_step: bad arguments");
+    // hyper-parameters arrive as the Python doubles torch uses: 1 - beta, the bias corrections and lr / bc1 are formed in double
+    // and rounded once, like the scalars torch hands to its kernels
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const SgAdamTensor*)tensors_dev,
+                       (const SgAdamChunk*)chunks_dev, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps);
+    SG_LAUNCH_CHECK();
+    return 0;
+}

@@ -6,7 +6,8 @@
   SRCycleGAN   -- full cycle of reference src/train.py:145-340 (G_A, G_B, D_A, D_B; GAN + cycle + identity).
   CasSRC       -- cascade of reference src/trainCas.py:18-153 (SR net + colouriser, two L1 losses).
 
-Networks and losses are the native modules of this package; optimisers stay ``torch.optim.Adam``
+Networks and losses are the native modules of this package; optimisers are ``torch.optim.Adam`` instances with a
+fused native ``step()`` (``srcgan_amd.optim.Adam``: same constructor, state and ``state_dict``)
 (surface requirement).
 """
 from __future__ import annotations
@@ -22,6 +23,7 @@ import torch.nn as nn
 from . import ops
 from .losses import GANLoss, L1Loss, PSNRLoss
 from .model import NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
+from .optim import Adam
 
 __all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasParams", "set_requires_grad"]
 
@@ -49,8 +51,8 @@ class PairedSRGAN:
         self.criterionGAN = GANLoss("lsgan", device=self.device)
         self.criterionL1 = L1Loss()
         self.lambda_l1 = lambda_l1
-        self.optimizer_G = torch.optim.Adam(self.netG.parameters(), lr=lr_g, betas=(beta1, 0.999))
-        self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=lr_d, betas=(beta1, 0.999))
+        self.optimizer_G = Adam(self.netG.parameters(), lr=lr_g, betas=(beta1, 0.999))      # a torch.optim.Adam with a fused step()
+        self.optimizer_D = Adam(self.netD.parameters(), lr=lr_d, betas=(beta1, 0.999))
         self.grad_sync = None      # srcgan_amd.dist.GradSync (data parallel) or None
 
     def _sync(self, params):
@@ -150,9 +152,9 @@ class SRCycleGAN:
         self.criterionGAN = GANLoss("lsgan", device=dev)
         self.criterionCycle = L1Loss()
         self.criterionIdt = L1Loss()
-        self.optimizer_G = torch.optim.Adam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
+        self.optimizer_G = Adam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
                                             lr=opt.lr, betas=(opt.beta1, 0.999))
-        self.optimizer_D = torch.optim.Adam(itertools.chain(self.netD_A.parameters(), self.netD_B.parameters()),
+        self.optimizer_D = Adam(itertools.chain(self.netD_A.parameters(), self.netD_B.parameters()),
                                             lr=1e-5, betas=(opt.beta1, 0.999))
         self.optimizers = [self.optimizer_G, self.optimizer_D]
         self.grad_sync = None
@@ -244,8 +246,8 @@ class CasSRC:
         self.netG_A2C = sr(1, 1, opt.up).to(opt.device)
         self.netG_C2B = (cm(1, 3, 1) if cm is RDDBNet else cm(1, 3)).to(opt.device)
         self.criterionSR, self.criterionC, self.criterionPSNR = L1Loss(), L1Loss(), PSNRLoss()
-        self.optimizer_G = torch.optim.Adam(self.netG_A2C.parameters(), lr=opt.lr)
-        self.optimizer_D = torch.optim.Adam(self.netG_C2B.parameters(), lr=opt.lr)
+        self.optimizer_G = Adam(self.netG_A2C.parameters(), lr=opt.lr)
+        self.optimizer_D = Adam(self.netG_C2B.parameters(), lr=opt.lr)
         self.optimizers = [self.optimizer_G, self.optimizer_D]
         self.init_log()
 

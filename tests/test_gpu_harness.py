@@ -140,3 +140,37 @@ def test_cycle_step_with_reference_g_a_vs_oracle():
             assert abs(float(mine[k]) - v) < 1e-3 * max(1.0, abs(v)), (step, k, float(mine[k]), v)
     for k, v in m.netG_A.state_dict().items():
         assert rel_err(v.cpu(), st.ga[k].detach()) < 2e-3, k
+
+
+def test_fused_adam_matches_torch_adam():
+    """srcgan_amd.optim.Adam (one native launch per group) against torch.optim.Adam over several steps, both beta1 settings the
+    reference uses (0.9 default, 0.5 for the GAN), odd sizes; state_dict interchange; fallback for unsupported options."""
+    from srcgan_amd.optim import Adam, fuse
+    for betas in ((0.9, 0.999), (0.5, 0.999)):
+        torch.manual_seed(4)
+        shapes = [(64, 3, 3, 3), (64,), (32, 160, 3, 3), (1,), (5000,), (3, 7)]
+        pa = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+        pb = [p.detach().clone().requires_grad_(True) for p in pa]
+        oa, ob = Adam(pa, lr=1e-3, betas=betas), torch.optim.Adam(pb, lr=1e-3, betas=betas, foreach=False)
+        assert isinstance(oa, torch.optim.Adam)
+        for step in range(4):
+            for a, b in zip(pa, pb):
+                g = torch.randn_like(a)
+                a.grad, b.grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+        sa, sb = oa.state_dict(), ob.state_dict()
+        assert sa["state"].keys() == sb["state"].keys()
+        for k in sa["state"]:
+            assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 4
+            assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+        ob.load_state_dict(sa)                         # checkpoints interchange
+        oa.load_state_dict(ob.state_dict())
+    # an existing torch.optim.Adam instance converts in place; unsupported options take torch's own step
+    q = [torch.randn(10, device="cuda").requires_grad_(True)]
+    o = fuse(torch.optim.Adam(q, lr=1e-2, weight_decay=0.1))
+    q[0].grad = torch.ones_like(q[0])
+    before = q[0].detach().clone()
+    o.step()
+    assert type(o) is Adam and not torch.equal(before, q[0])
