@@ -7,6 +7,7 @@ foreach kernel sequence -- 697 tensors for the 23-block generator.  Option combi
 (weight decay, amsgrad, maximize, capturable, differentiable, non-f32 or CPU parameters) fall back to torch's own step.
 ``fuse(optimizer)`` converts an existing ``torch.optim.Adam`` instance in place (what the reference harness constructs).
 """
+import os
 from typing import List
 
 import numpy as np
@@ -17,6 +18,7 @@ from . import _native as N
 __all__ = ["Adam", "fuse"]
 
 _CHUNK = 4096
+_DISABLED = bool(os.environ.get("SRCGAN_TORCH_ADAM"))      # A/B switch for bench.py
 
 
 class Adam(torch.optim.Adam):
@@ -26,7 +28,7 @@ class Adam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
-        if not all(self._fusable(g) for g in self.param_groups) or any(
+        if _DISABLED or not all(self._fusable(g) for g in self.param_groups) or any(
                 p.grad is not None and (not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse
                                         or not p.is_contiguous() or not p.grad.is_contiguous())
                 for g in self.param_groups for p in g["params"]):
@@ -61,11 +63,18 @@ class Adam(torch.optim.Adam):
                 off = np.concatenate([np.arange(0, n, _CHUNK, dtype=np.int32) for n in shapes])
                 cnt = np.minimum(np.array(shapes, dtype=np.int64)[tid] - off, _CHUNK).astype(np.int32)
                 chunks = np.stack([tid, off, cnt, np.zeros_like(tid)], axis=1)
-                ent = {"shapes": shapes, "chunks": torch.from_numpy(chunks).to(ps[0].device), "n": int(len(tid)), "ptrs": None, "tensors": None}
+                ent = {"shapes": shapes, "chunks": torch.from_numpy(chunks).to(ps[0].device), "n": int(len(tid)), "ptrs": None,
+                       "tensors": torch.empty(len(ps) * 4, dtype=torch.int64, device=ps[0].device),
+                       # two pinned staging buffers, used alternately: the upload is asynchronous (a pageable copy would make the
+                       # host wait for the whole backward pass queued on the stream) and at most one step is in flight behind it
+                       "pinned": [torch.empty(len(ps) * 4, dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0}
                 cache[gi] = ent
-            if ent["ptrs"] is None or not np.array_equal(ent["ptrs"], ptrs):
+            if ent["ptrs"] is None or not np.array_equal(ent["ptrs"], ptrs):      # fresh .grad tensors move between steps
                 ent["ptrs"] = ptrs
-                ent["tensors"] = torch.from_numpy(ptrs.view(np.int64).copy()).to(ps[0].device)     # 697 x 32 B; fresh .grad tensors move
+                stage = ent["pinned"][ent["flip"]]
+                ent["flip"] ^= 1
+                stage.numpy()[:] = ptrs.view(np.int64).reshape(-1)
+                ent["tensors"].copy_(stage, non_blocking=True)
             b1, b2 = group["betas"]
             N.check(lib.srcgan_adam_step(ent["tensors"].data_ptr(), ent["chunks"].data_ptr(), ent["n"], float(group["lr"]), float(b1), float(b2),
                                          float(group["eps"]), steps.pop(), N.stream_ptr(ps[0].device)), "srcgan_adam_step")
