@@ -235,6 +235,8 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
     SG_CASE(3, 3, 2, 1, false)
     SG_CASE(7, 7, 2, 1, true)        // ResDeconv stem (resdeconv.py:113)
     SG_CASE(1, 1, 2, 2, false)       // ResDeconv down-sample shortcut (resdeconv.py:12-15,157-161)
+    SG_CASE(5, 5, 1, 2, true)        // ESPCN conv1 (espcn.py:33), SRCNN conv3 (srcnn.py:36)
+    SG_CASE(9, 9, 1, 2, true)        // SRCNN conv1 (srcnn.py:32)
 #undef SG_CASE
     SG_FAIL("srcgan_conv_igemm: unsupported kernel %dx%d stride %d", kh, kw, s);
 }

@@ -329,6 +329,9 @@ static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st
     SG_CASE(4, 4, 1, 8, 4, false)
     SG_CASE(3, 3, 2, 4, 3, true)
     SG_CASE(1, 1, 2, 4, 4, false)
+    SG_CASE(1, 1, 1, 8, 4, false)
+    SG_CASE(5, 5, 1, 8, 7, false)
+    if constexpr (MT == 1) { SG_CASE(9, 9, 1, 8, 9, false) }
     if constexpr (MT == 1) { SG_CASE(7, 7, 2, 4, 8, false) }     // 49 taps: 7 per wave x 16 accumulator registers, 32-row tiles only
 #undef SG_CASE
     SG_FAIL("srcgan_conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, s);
@@ -354,7 +357,7 @@ extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = cin_r; p.xCs = d->x_cs; p.xcoff = d->x_coff;
     p.OH = d->OH; p.OW = d->OW; p.Cout = cout_r; p.dyCs = d->dy_cs; p.dycoff = d->dy_coff;
     p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.want_bias = d->bias_grad != nullptr;
-    const int cot = d->kh == 7 ? 32 : wg_cot(d->Cout);
+    const int cot = d->kh >= 7 ? 32 : wg_cot(d->Cout);     // 49 / 81 taps: the per-wave accumulators only fit for 32-row tiles
     p.ctiles = cdiv(d->Cout, cot); p.citiles = cdiv(d->Cin, 32);
     const int th = d->stride == 2 ? 4 : 8;
     const long ntiles = (long)d->B * cdiv(d->OH, th) * cdiv(d->OW, 32);

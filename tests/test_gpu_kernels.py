@@ -388,7 +388,8 @@ def test_group_norm_fwd_bwd(ops, dt, C, hw, relu, res):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("k,s,pad,cin,cout,hw", [(7, 2, 3, 3, 64, (32, 44)), (7, 2, 3, 3, 64, (17, 9)), (1, 2, 0, 64, 128, (16, 24)), (1, 2, 0, 256, 512, (9, 7))])
+@pytest.mark.parametrize("k,s,pad,cin,cout,hw", [(7, 2, 3, 3, 64, (32, 44)), (7, 2, 3, 3, 64, (17, 9)), (1, 2, 0, 64, 128, (16, 24)), (1, 2, 0, 256, 512, (9, 7)),
+                                               (5, 1, 2, 1, 64, (20, 33)), (5, 1, 2, 32, 3, (12, 40)), (9, 1, 4, 3, 64, (18, 35)), (1, 1, 0, 64, 32, (10, 12))])
 def test_stem_and_shortcut_convs(ops, dt, k, s, pad, cin, cout, hw):
     torch.manual_seed(32)
     H, W = hw
@@ -400,10 +401,11 @@ def test_stem_and_shortcut_convs(ops, dt, k, s, pad, cin, cout, hw):
     OH, OW = y.shape[2:]
     cs = max(8, cin)
     xg = _nhwc(ops, x.detach(), cs, dt)
-    yg = torch.zeros(2, OH, OW, cout, device="cuda", dtype=xg.dtype)
+    ycs = max(8, cout)
+    yg = torch.zeros(2, OH, OW, ycs, device="cuda", dtype=xg.dtype)
     wp = ops.pack_weight(w.detach().cuda(), cout, cin, k, k, cin * k * k, k * k, k, 1, 0, dt)
     ops.conv_igemm(xg, wp, yg, kh=k, kw=k, stride=s, Cin=cs, Cout=cout, pad=(pad, pad))      # image channels are zero-padded to 8
-    assert rel_err(ops.to_nchw(yg).cpu(), y.detach()) < TOL[dt]
+    assert rel_err(ops.to_nchw(yg, cout).cpu(), y.detach()) < TOL[dt]
     gw = torch.zeros(cout, cin, k, k, device="cuda")
-    ops.conv_wgrad(_nhwc(ops, dy, cout, dt), xg, gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(pad, pad), layout=(cin * k * k, k * k, k, 1, 0))
+    ops.conv_wgrad(_nhwc(ops, dy, ycs, dt), xg, gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(pad, pad), layout=(cin * k * k, k * k, k, 1, 0))
     assert rel_err(gw.cpu(), w.grad) < TOL[dt]
