@@ -284,6 +284,27 @@ int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw,
 int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws,
                               void* scratch, float* const* grads, void* stream);
 
+/* Small SR networks selectable as --SRModel (trainCas.py:169): kind 0 = ESPCN (espcn.py:18-51; the CLI default), kind 1 = SRCNN
+ * (srcnn.py:17-42).  [B,in_ch,H,W] f32 NCHW -> ESPCN [B,out_ch,H*up,W*up] / SRCNN [B,out_ch,H,W].  params/grads in state_dict
+ * order (conv1.weight, conv1.bias, ...).  No gradient w.r.t. the input. */
+typedef struct srcgan_srnet_cfg {
+    int kind, in_ch, out_ch, up, base;     /* base = base_kernel (64) */
+    int B, H, W;
+    int dtype;
+} srcgan_srnet_cfg;
+int srcgan_srnet_num_params(const srcgan_srnet_cfg* c);
+size_t srcgan_srnet_ws_bytes(const srcgan_srnet_cfg* c);
+size_t srcgan_srnet_bwd_scratch_bytes(const srcgan_srnet_cfg* c);
+int srcgan_srnet_forward(const srcgan_srnet_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* stream);
+int srcgan_srnet_backward(const srcgan_srnet_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
+                          float* const* grads, void* stream);
+
+/* nn.PixelShuffle(r) on NHWC (espcn.py:44,50): src [B,H,W,C*r*r] -> dst [B,H*r,W*r,C]; inverse = 1: the adjoint, src [B,H*r,W*r,C]
+ * -> dst [B,H,W,C*r*r].  srcgan_mask_inplace: g *= (act > 0 ? 1 : slope) over n elements (ReLU' / LeakyReLU' on an incoming gradient). */
+int srcgan_pixel_shuffle_nhwc(const void* src, int s_cs, void* dst, int d_cs, int B, int H, int W, int C, int r, int inverse,
+                              int dtype, void* stream);
+int srcgan_mask_inplace(void* g, const void* act, float slope, long n, int dtype, void* stream);
+
 /* Fused multi-tensor Adam (torch.optim.Adam.step() of trainCas.py:38-41,143-150 / train.py:191-192,331-340; torch's
  * single-tensor arithmetic, default flags: no weight decay, no amsgrad).  tensors_dev: device array of records
  * {float* p; const float* g; float* m; float* v;} (32 bytes); chunks_dev: device array of nchunks records

@@ -32,7 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
-    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward",
 ]
 
 
@@ -163,6 +163,19 @@ def resdeconv_forward(sd: State, x: Tensor) -> Tensor:
         t = _rd_block(sd, f"{name}.1.", t, 1)
     t = F.conv_transpose2d(t, sd["deconv13.weight"], None, 2, 0)
     return F.conv2d(t, sd["pred.weight"], None, 1, 1)
+
+
+def espcn_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
+    """ESPCN.forward, espcn.py:46-51."""
+    c = lambda n, t: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], 1, sd[n + ".weight"].shape[-1] // 2)
+    t = F.relu(c("conv1", x)); t = F.relu(c("conv2", t)); t = F.relu(c("conv3", t))
+    return c("conv5", F.pixel_shuffle(c("conv4", t), upscale_factor))
+
+
+def srcnn_forward(sd: State, x: Tensor) -> Tensor:
+    """SRCNN.forward, srcnn.py:38-42 (ReLU after every convolution, the last included)."""
+    c = lambda n, t: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], 1, sd[n + ".weight"].shape[-1] // 2)
+    return F.relu(c("conv3", F.relu(c("conv2", F.relu(c("conv1", x))))))
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:

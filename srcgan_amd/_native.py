@@ -88,6 +88,10 @@ class ResDeconvCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
 
 
+class SrNetCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("kind", "in_ch", "out_ch", "up", "base", "B", "H", "W", "dtype")]
+
+
 class NLayerDCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("ndf", C.c_int), ("n_layers", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
@@ -136,6 +140,13 @@ SIGNATURES = {
     "srcgan_resdeconv_bwd_scratch_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_forward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P]),
     "srcgan_resdeconv_backward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P, _P]),
+    "srcgan_srnet_num_params": (_I, [C.POINTER(SrNetCfg)]),
+    "srcgan_srnet_ws_bytes": (_S, [C.POINTER(SrNetCfg)]),
+    "srcgan_srnet_bwd_scratch_bytes": (_S, [C.POINTER(SrNetCfg)]),
+    "srcgan_srnet_forward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P]),
+    "srcgan_srnet_backward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P, _P]),
+    "srcgan_pixel_shuffle_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "srcgan_mask_inplace": (_I, [_P, _P, _F, _L, _I, _P]),
     "srcgan_adam_step": (_I, [_P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _L, _P]),
     "srcgan_prof_enable": (_I, [_I]),
     "srcgan_prof_collect": (_I, []),

@@ -757,6 +757,46 @@ extern "C" int srcgan_nearest_resize(const float* src, float* dst, int B, int C,
     return 0;
 }
 
+// --------------------------------------------------------------------------- PixelShuffle / activation mask
+// nn.PixelShuffle(r) on NHWC (espcn.py:44,50; edsr.py:57-66): out[b][y*r+a][x*r+c][ch] = in[b][y][x][ch*r*r + a*r + c];
+// inverse = 1 runs the adjoint (gradient) direction: in[b][y][x][ch*r*r + a*r + c] = out[b][y*r+a][x*r+c][ch].
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_shuffle_nhwc_k(const T* __restrict__ src, int s_cs, T* __restrict__ dst, int d_cs,
+                                                            int H, int W, int C, int r, int inverse, long total) {
+    // thread per element of the LOW-resolution tensor [B,H,W,C*r*r]
+    const int Cr = C * r * r;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int cc = (int)(e % Cr); long q = e / Cr;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H); const long b = q / H;
+        const int ch = cc / (r * r), ab = cc % (r * r), a = ab / r, c = ab % r;
+        const long lo = ((b * H + y) * W + x), hi = ((b * H * r + (long)y * r + a) * W * r + (long)x * r + c);
+        if (inverse) dst[lo * d_cs + cc] = src[hi * s_cs + ch];
+        else dst[hi * d_cs + ch] = src[lo * s_cs + cc];
+    }
+}
+extern "C" int srcgan_pixel_shuffle_nhwc(const void* src, int s_cs, void* dst, int d_cs, int B, int H, int W, int C, int r, int inverse,
+                                         int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && r >= 1, "srcgan_pixel_shuffle_nhwc: bad arguments");
+    const long total = (long)B * H * W * C * r * r;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pixel_shuffle_nhwc_k<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)src, s_cs, (T*)dst, d_cs, H, W, C, r, inverse, total));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+// g *= act > 0 ? 1 : slope  (gradient of ReLU / LeakyReLU applied to a gradient arriving from outside the network)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_inplace_k(T* __restrict__ g, const T* __restrict__ act, float slope, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        if (!(to_f(act[e]) > 0.f)) g[e] = from_f<T>(to_f(g[e]) * slope);
+}
+extern "C" int srcgan_mask_inplace(void* g, const void* act, float slope, long n, int dtype, void* stream) {
+    SG_REQUIRE(g && act && n > 0, "srcgan_mask_inplace: bad arguments");
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(mask_inplace_k<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (T*)g, (const T*)act, slope, n));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 // --------------------------------------------------------------------------- fused multi-tensor Adam
 // One launch updates every parameter of an optimiser group (697 tensors for the 23-block generator): replaces the
 // foreach kernels behind torch.optim.Adam.step() (reference trainCas.py:38-41,143-150; train.py:191-192,331-340) with the

@@ -829,61 +829,68 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
     return 0;
 }
 
-// ======================================================================================== ResDeconv colouriser
-// Reference src/model/resdeconv.py:99-195 (the second network of every trainCas step, trainCas.py:31,99-100):
-// ResNet-18-style encoder (7x7 s2 stem, BasicBlocks 64-128-256-512 with 3x3 s2 + 1x1 s2 shortcut at each widening) and a
-// mirrored decoder (ConvTranspose2d k2 s2 + two BasicBlocks per scale), GroupNorm(32) + ReLU everywhere, no biases.
-// The network is a short op list built once per call; forward walks it, backward walks it in reverse.  A tensor with two
-// consumers (a block's input: first convolution + shortcut) gets its first gradient contribution by a plain store and
-// the second through the convolution epilogue's in-place residual operand.
+// ======================================================================================== op-list networks
+// ResDeconv colouriser -- reference src/model/resdeconv.py:99-195 (the second network of every trainCas step,
+// trainCas.py:31,99-100): ResNet-18-style encoder (7x7 s2 stem, BasicBlocks 64-128-256-512 with 3x3 s2 + 1x1 s2 shortcut at
+// each widening) and a mirrored decoder (ConvTranspose2d k2 s2 + two BasicBlocks per scale), GroupNorm(32) + ReLU, no biases.
+// ESPCN -- src/model/espcn.py:18-51 (the CLI default --SRModel, trainCas.py:169): 5x5, 3x3, 3x3 convs + ReLU, 3x3 conv to
+// 64 r^2 channels, PixelShuffle(r), 3x3 conv.   SRCNN -- src/model/srcnn.py:17-42: 9x9, 1x1, 5x5 convs, each + ReLU.
+//
+// Each network is a short op list built once per call; forward walks it, backward walks it in reverse.  A tensor with two
+// consumers (a block's input: first convolution + shortcut) gets its first gradient contribution by a plain store and the
+// second through the convolution epilogue's in-place residual operand.  The gradient stored for the output of a
+// convolution with a fused ReLU is the gradient w.r.t. its pre-activation: whoever writes it applies the mask (the consumer's
+// dgrad epilogue, or srcgan_mask_inplace for the gradient arriving from the loss).
 namespace {
-struct RdT { int C, cs, H, W; size_t off; };
+struct RdT { int C, cs, H, W, act; size_t off; };       // act: produced by a convolution with a fused ReLU
 struct RdOp {
-    int type;                 // 0 conv, 1 GroupNorm(+res)(+ReLU), 2 ConvTranspose2d k2 s2
+    int type;                 // 0 conv (+bias)(+ReLU), 1 GroupNorm(+res)(+ReLU), 2 ConvTranspose2d k2 s2, 3 PixelShuffle(r)
     int in, out, res, relu;
-    int k, s, pad, w;         // w: parameter index of the weight (GroupNorm: gamma, beta = w + 1)
+    int k, s, pad, w, bias;   // w: parameter index of the weight (GroupNorm: gamma, beta = w + 1); bias: parameter index or -1
     size_t wf[4], wd[4], stats;
 };
 struct RdPlan {
-    int dtype, esz, B, H, W, in_ch, out_ch, in_cs, out_cs, nparams;
+    int dtype, esz, B, H, W, in_ch, out_ch, in_cs, out_cs, nparams, maxC;
     std::vector<RdT> T; std::vector<RdOp> ops;
     size_t xin, gnfwd, wpk, total, act_bytes;
     std::vector<size_t> g;    // backward: gradient buffer offsets (scratch), same shapes as T
-    size_t slab, gnscr, bwd_total;
+    size_t slab, gnscr, colscr, bwd_total;
 };
 
-static int rd_plan(const srcgan_resdeconv_cfg* c, RdPlan& P) {
-    SG_REQUIRE(c, "resdeconv: null cfg");
-    SG_REQUIRE(c->dtype == SRCGAN_F32 || c->dtype == SRCGAN_BF16, "resdeconv: bad dtype %d", c->dtype);
-    SG_REQUIRE(c->in_ch == 3 && c->out_ch > 0 && c->out_ch <= 8, "resdeconv: the stem takes 3 channels (resdeconv.py:113), tar_ch must be in 1..8");
-    SG_REQUIRE(c->B > 0 && c->H > 0 && c->W > 0 && c->H % 16 == 0 && c->W % 16 == 0, "resdeconv: H and W must be multiples of 16 (four stride-2 stages mirrored by four x2 deconvolutions)");
-    P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
-    P.B = c->B; P.H = c->H; P.W = c->W; P.in_ch = c->in_ch; P.out_ch = c->out_ch; P.in_cs = img_cs(c->in_ch); P.out_cs = img_cs(c->out_ch);
-    Bump b;
-    int np = 0;
-    auto tensor = [&](int C, int cs, int H, int W) { P.T.push_back(RdT{C, cs, H, W, b.take((size_t)c->B * H * W * cs * P.esz)}); return (int)P.T.size() - 1; };
-    auto conv = [&](int in, int cout, int k, int s, int pad) {
+struct RdBuilder {
+    RdPlan& P; Bump b; int np = 0; int B;
+    RdBuilder(RdPlan& p, int B_) : P(p), B(B_) {}
+    int tensor(int C, int cs, int H, int W, int act = 0) { P.T.push_back(RdT{C, cs, H, W, act, b.take((size_t)B * H * W * cs * P.esz)}); return (int)P.T.size() - 1; }
+    int conv(int in, int cout, int k, int s, int pad, bool bias = false, bool relu = false) {
         const RdT ti = P.T[in];
         const int oh = (ti.H + 2 * pad - k) / s + 1, ow = (ti.W + 2 * pad - k) / s + 1;
         RdOp o; memset(&o, 0, sizeof(o));
-        o.type = 0; o.in = in; o.out = tensor(cout, cout < 8 ? 8 : cout, oh, ow); o.res = -1; o.k = k; o.s = s; o.pad = pad; o.w = np++;
+        o.type = 0; o.in = in; o.res = -1; o.k = k; o.s = s; o.pad = pad; o.relu = relu; o.w = np++; o.bias = bias ? np++ : -1;
+        o.out = tensor(cout, cout < 8 ? 8 : cout, oh, ow, relu);
         P.ops.push_back(o); return o.out;
-    };
-    auto gn = [&](int in, int res, int relu) {
+    }
+    int gn(int in, int res, int relu) {
         const RdT ti = P.T[in];
         RdOp o; memset(&o, 0, sizeof(o));
-        o.type = 1; o.in = in; o.out = tensor(ti.C, ti.cs, ti.H, ti.W); o.res = res; o.relu = relu; o.w = np; np += 2;
-        o.stats = b.take((size_t)c->B * 32 * 2 * sizeof(float));
+        o.type = 1; o.in = in; o.out = tensor(ti.C, ti.cs, ti.H, ti.W); o.res = res; o.relu = relu; o.w = np; np += 2; o.bias = -1;
+        o.stats = b.take((size_t)B * 32 * 2 * sizeof(float));
         P.ops.push_back(o); return o.out;
-    };
-    auto deconv_ = [&](int in, int cout) {
+    }
+    int deconv(int in, int cout) {
         const RdT ti = P.T[in];
         RdOp o; memset(&o, 0, sizeof(o));
-        o.type = 2; o.in = in; o.out = tensor(cout, cout, 2 * ti.H, 2 * ti.W); o.res = -1; o.k = 2; o.s = 2; o.w = np++;
+        o.type = 2; o.in = in; o.out = tensor(cout, cout, 2 * ti.H, 2 * ti.W); o.res = -1; o.k = 2; o.s = 2; o.w = np++; o.bias = -1;
         P.ops.push_back(o); return o.out;
-    };
+    }
+    int shuffle(int in, int r) {
+        const RdT ti = P.T[in];
+        RdOp o; memset(&o, 0, sizeof(o));
+        o.type = 3; o.in = in; o.res = -1; o.k = r; o.w = -1; o.bias = -1;
+        o.out = tensor(ti.C / (r * r), ti.C / (r * r), ti.H * r, ti.W * r);
+        P.ops.push_back(o); return o.out;
+    }
     // BasicBlock (resdeconv.py:56-97).  state_dict order inside a block: conv1, bn1, conv2, bn2, downsample.{0,1}
-    auto block = [&](int x, int planes, int stride) {
+    int block(int x, int planes, int stride) {
         const bool ds = stride != 1 || P.T[x].C != planes;
         int t = conv(x, planes, 3, stride, 1);
         t = gn(t, -1, 1);
@@ -894,70 +901,117 @@ static int rd_plan(const srcgan_resdeconv_cfg* c, RdPlan& P) {
         const int out = gn(t, idn, 1);
         P.ops.back().w = gn2_param; np -= 2;
         return out;
-    };
-    P.xin = b.take((size_t)c->B * c->H * c->W * P.in_cs * P.esz);
-    P.T.push_back(RdT{c->in_ch, P.in_cs, c->H, c->W, P.xin});
-    int t = conv(0, 64, 7, 2, 3);
-    P.ops.back().in = 0;
-    t = gn(t, -1, 1);
-    const int widths[4] = {64, 128, 256, 512};
-    for (int l = 0; l < 4; ++l) { t = block(t, widths[l], l == 0 ? 1 : 2); t = block(t, widths[l], 1); }
-    const int up_w[3] = {256, 128, 64};
-    for (int l = 0; l < 3; ++l) { t = deconv_(t, up_w[l]); t = block(t, up_w[l], 1); t = block(t, up_w[l], 1); }
-    t = deconv_(t, 64);
-    t = conv(t, c->out_ch, 3, 1, 1);
-    P.nparams = np;
-    P.gnfwd = b.take(srcgan_gn_scratch_floats(c->B, 512) * sizeof(float));
-    P.act_bytes = b.off;
-    // packed weights
-    P.wpk = b.off;
-    Bump wb;
-    auto pk = [&](int rows, int k, int taps) { return wb.take(srcgan_packed_weight_bytes(rows, k, taps, c->dtype)); };
-    for (RdOp& o : P.ops) {
-        const RdT ti = P.T[o.in], to = P.T[o.out];
-        if (o.type == 0) {
-            o.wf[0] = pk(to.C, ti.C, o.k * o.k);
-            if (o.in != 0) {
-                if (o.s == 1) o.wd[0] = pk(ti.C, to.C, o.k * o.k);
-                else if (o.k == 1) o.wd[0] = pk(ti.C, to.C, 1);
-                else for (int q = 0; q < 4; ++q) o.wd[q] = pk(ti.C, to.C, ((q >> 1) ? 2 : 1) * ((q & 1) ? 2 : 1));
+    }
+    void input(int in_ch, int H, int W) {
+        P.in_ch = in_ch; P.in_cs = img_cs(in_ch); P.H = H; P.W = W;
+        P.xin = b.take((size_t)B * H * W * P.in_cs * P.esz);
+        P.T.push_back(RdT{in_ch, P.in_cs, H, W, 0, P.xin});
+    }
+    void finish(int dtype) {
+        P.nparams = np;
+        P.maxC = 8;
+        for (const RdT& t : P.T) if (t.C > P.maxC) P.maxC = t.C;
+        P.out_ch = P.T.back().C; P.out_cs = P.T.back().cs;
+        P.gnfwd = b.take(srcgan_gn_scratch_floats(B, P.maxC > 1024 ? 1024 : P.maxC) * sizeof(float));
+        P.act_bytes = b.off;
+        P.wpk = b.off;
+        Bump wb;
+        auto pk = [&](int rows, int k, int taps) { return wb.take(srcgan_packed_weight_bytes(rows, k, taps, dtype)); };
+        for (RdOp& o : P.ops) {
+            const RdT ti = P.T[o.in], to = P.T[o.out];
+            if (o.type == 0) {
+                o.wf[0] = pk(to.C, ti.C, o.k * o.k);
+                if (o.in != 0) {
+                    if (o.s == 1) o.wd[0] = pk(ti.C, to.C, o.k * o.k);
+                    else if (o.k == 1) o.wd[0] = pk(ti.C, to.C, 1);
+                    else for (int q = 0; q < 4; ++q) o.wd[q] = pk(ti.C, to.C, ((q >> 1) ? 2 : 1) * ((q & 1) ? 2 : 1));
+                }
+            } else if (o.type == 2) {
+                for (int q = 0; q < 4; ++q) o.wf[q] = pk(to.C, ti.C, 1);
+                o.wd[0] = pk(ti.C, to.C, 4);
             }
-        } else if (o.type == 2) {
-            for (int q = 0; q < 4; ++q) o.wf[q] = pk(to.C, ti.C, 1);
-            o.wd[0] = pk(ti.C, to.C, 4);
         }
+        P.total = align_up(P.wpk + wb.off + 256, 256);
+        // backward scratch
+        Bump s;
+        P.g.resize(P.T.size());
+        long maxpix = 1;
+        for (size_t i = 0; i < P.T.size(); ++i) {
+            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
+            if ((long)B * P.T[i].H * P.T[i].W > maxpix) maxpix = (long)B * P.T[i].H * P.T[i].W;
+        }
+        size_t slab = 0;
+        for (const RdOp& o : P.ops) {
+            const RdT ti = P.T[o.in], to = P.T[o.out];
+            size_t v = 0;
+            if (o.type == 0) v = wgrad_slab(B, to.H, to.W, to.C, ti.C, o.k, o.k, o.s);
+            else if (o.type == 2) v = wgrad_slab(B, ti.H, ti.W, ti.C, to.C, 2, 2, 2);
+            if (v > slab) slab = v;
+        }
+        P.slab = s.take(slab);
+        P.gnscr = s.take(srcgan_gn_scratch_floats(B, P.maxC > 1024 ? 1024 : P.maxC) * sizeof(float));
+        P.colscr = s.take((size_t)2 * srcgan_col_reduce_blocks(maxpix) * P.maxC * sizeof(float));
+        P.bwd_total = s.off + 256;
     }
-    P.total = align_up(P.wpk + wb.off + 256, 256);
-    // backward scratch
-    Bump s;
-    P.g.resize(P.T.size());
-    for (size_t i = 0; i < P.T.size(); ++i) P.g[i] = i == 0 ? 0 : s.take((size_t)c->B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
-    size_t slab = 0;
-    for (const RdOp& o : P.ops) {
-        const RdT ti = P.T[o.in], to = P.T[o.out];
-        size_t v = 0;
-        if (o.type == 0) v = wgrad_slab(c->B, to.H, to.W, to.C, ti.C, o.k, o.k, o.s);
-        else if (o.type == 2) v = wgrad_slab(c->B, ti.H, ti.W, ti.C, to.C, 2, 2, 2);
-        if (v > slab) slab = v;
+};
+
+static int rd_common(int dtype, int B, int H, int W, RdPlan& P, const char* who) {
+    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "%s: bad dtype %d", who, dtype);
+    SG_REQUIRE(B > 0 && H > 0 && W > 0, "%s: bad B/H/W", who);
+    P.dtype = dtype; P.esz = dtype == SRCGAN_F32 ? 4 : 2; P.B = B;
+    return 0;
+}
+
+static int rd_plan(const srcgan_resdeconv_cfg* c, RdPlan& P) {
+    SG_REQUIRE(c, "resdeconv: null cfg");
+    SG_TRY(rd_common(c->dtype, c->B, c->H, c->W, P, "resdeconv"));
+    SG_REQUIRE(c->in_ch == 3 && c->out_ch > 0 && c->out_ch <= 8, "resdeconv: the stem takes 3 channels (resdeconv.py:113), tar_ch must be in 1..8");
+    SG_REQUIRE(c->H % 16 == 0 && c->W % 16 == 0, "resdeconv: H and W must be multiples of 16 (four stride-2 stages mirrored by four x2 deconvolutions)");
+    RdBuilder nb(P, c->B);
+    nb.input(c->in_ch, c->H, c->W);
+    int t = nb.conv(0, 64, 7, 2, 3);
+    t = nb.gn(t, -1, 1);
+    const int widths[4] = {64, 128, 256, 512};
+    for (int l = 0; l < 4; ++l) { t = nb.block(t, widths[l], l == 0 ? 1 : 2); t = nb.block(t, widths[l], 1); }
+    const int up_w[3] = {256, 128, 64};
+    for (int l = 0; l < 3; ++l) { t = nb.deconv(t, up_w[l]); t = nb.block(t, up_w[l], 1); t = nb.block(t, up_w[l], 1); }
+    t = nb.deconv(t, 64);
+    nb.conv(t, c->out_ch, 3, 1, 1);
+    nb.finish(c->dtype);
+    return 0;
+}
+
+// kind 0: ESPCN(in_ch, ou_ch, upscale_factor, base_kernel) espcn.py:18-51;  kind 1: SRCNN(in_ch, ou_ch, ., base_kernel) srcnn.py:17-42
+static int sr_plan(const srcgan_srnet_cfg* c, RdPlan& P) {
+    SG_REQUIRE(c, "srnet: null cfg");
+    SG_TRY(rd_common(c->dtype, c->B, c->H, c->W, P, "srnet"));
+    SG_REQUIRE(c->kind == 0 || c->kind == 1, "srnet: kind must be 0 (ESPCN) or 1 (SRCNN)");
+    SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8 && c->out_ch > 0 && c->out_ch <= 8, "srnet: in/out channels must be in 1..8");
+    SG_REQUIRE(c->base > 0 && c->base % 16 == 0, "srnet: base_kernel must be a multiple of 16");
+    SG_REQUIRE(c->up >= 1 && c->up <= 8, "srnet: upscale_factor must be in 1..8");
+    RdBuilder nb(P, c->B);
+    nb.input(c->in_ch, c->H, c->W);
+    if (c->kind == 0) {
+        int t = nb.conv(0, c->base, 5, 1, 2, true, true);
+        t = nb.conv(t, c->base, 3, 1, 1, true, true);
+        t = nb.conv(t, c->base / 2, 3, 1, 1, true, true);
+        t = nb.conv(t, c->base * c->up * c->up, 3, 1, 1, true, false);
+        t = nb.shuffle(t, c->up);
+        nb.conv(t, c->out_ch, 3, 1, 1, true, false);
+    } else {
+        int t = nb.conv(0, c->base, 9, 1, 4, true, true);
+        t = nb.conv(t, c->base / 2, 1, 1, 0, true, true);
+        nb.conv(t, c->out_ch, 5, 1, 2, true, true);
     }
-    P.slab = s.take(slab);
-    P.gnscr = s.take(srcgan_gn_scratch_floats(c->B, 512) * sizeof(float));
-    P.bwd_total = s.off + 256;
+    nb.finish(c->dtype);
     return 0;
 }
 static inline TRef rd_t(char* base, const RdT& t) { return tref(base + t.off, t.cs); }
-}  // namespace
 
-extern "C" int srcgan_resdeconv_num_params(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return -1; return P.nparams; }
-extern "C" size_t srcgan_resdeconv_ws_bytes(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return 0; return P.total; }
-extern "C" size_t srcgan_resdeconv_bwd_scratch_bytes(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return 0; return P.bwd_total; }
-
-extern "C" int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* st) {
-    RdPlan P;
-    SG_TRY(rd_plan(c, P));
-    SG_REQUIRE(x_nchw && params && ws && y_nchw, "srcgan_resdeconv_forward: null pointer");
-    SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_resdeconv_forward: workspace must be 256-byte aligned");
-    const int dt = c->dtype, B = c->B;
+static int rd_forward(const RdPlan& P, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, const char* tag, void* st) {
+    SG_REQUIRE(x_nchw && params && ws && y_nchw, "%s forward: null pointer", tag);
+    SG_REQUIRE(((uintptr_t)ws % 256) == 0, "%s forward: workspace must be 256-byte aligned", tag);
+    const int dt = P.dtype, B = P.B;
     char* w8 = (char*)ws; char* wp = w8 + P.wpk;
     PackList packs(dt, wp);
     for (const RdOp& o : P.ops) {
@@ -966,42 +1020,45 @@ extern "C" int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const flo
         else if (o.type == 2)
             for (int q = 0; q < 4; ++q) packs.add(params[o.w], wp + o.wf[q], to.C, ti.C, 1, 1, 4, (long)to.C * 4, 0, 0, q);
     }
-    SG_TRY(packs.run("resdeconv_fwd", params[0], st));
-    SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
+    char key[64]; snprintf(key, sizeof(key), "%s_fwd", tag);
+    SG_TRY(packs.run(key, params[0], st));
+    SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, P.in_ch, P.H, P.W, P.in_cs, dt, st));
     float* gnscr = (float*)(w8 + P.gnfwd);
     for (const RdOp& o : P.ops) {
         const RdT ti = P.T[o.in], to = P.T[o.out];
         TRef xin = rd_t(w8, ti), out = rd_t(w8, to);
         if (o.type == 0) {
             if (to.C < to.cs) SG_HIP(hipMemsetAsync(out.p, 0, (size_t)B * to.H * to.W * to.cs * P.esz, (hipStream_t)st));
-            SG_TRY(Conv(dt, o.k, o.k, o.s).in(xin, B, ti.H, ti.W, ti.C < 8 ? ti.cs : ti.C).w(wp + o.wf[0]).out(out, to.H, to.W, to.C).pad(o.pad, o.pad).run(st));
+            Conv cv(dt, o.k, o.k, o.s);
+            cv.in(xin, B, ti.H, ti.W, ti.C < 8 ? ti.cs : ti.C).w(wp + o.wf[0], o.bias >= 0 ? params[o.bias] : nullptr).out(out, to.H, to.W, to.C).pad(o.pad, o.pad);
+            if (o.relu) { cv.lrelu(); cv.d.slope = 0.f; }
+            SG_TRY(cv.run(st));
         } else if (o.type == 1) {
             const void* res = o.res >= 0 ? (w8 + P.T[o.res].off) : nullptr;
             SG_TRY(srcgan_gn_forward(xin.p, ti.cs, res, o.res >= 0 ? P.T[o.res].cs : 0, out.p, to.cs, params[o.w], params[o.w + 1],
                                      (float*)(w8 + o.stats), B, (long)ti.H * ti.W, ti.C, 32, 1e-5f, o.relu, dt, gnscr, st));
-        } else {
+        } else if (o.type == 2) {
             for (int q = 0; q < 4; ++q)
                 SG_TRY(Conv(dt, 1, 1, 1).in(xin, B, ti.H, ti.W, ti.C).w(wp + o.wf[q]).out(out, ti.H, ti.W, to.C)
                            .scatter(2, q >> 1, q & 1, to.H, to.W).run(st));
+        } else {
+            SG_TRY(srcgan_pixel_shuffle_nhwc(xin.p, ti.cs, out.p, to.cs, B, ti.H, ti.W, to.C, o.k, 0, dt, st));
         }
     }
     const RdT& last = P.T.back();
-    SG_TRY(srcgan_nhwc_to_nchw_f32(w8 + last.off, y_nchw, B, c->out_ch, last.H, last.W, last.cs, 0, dt, st));
+    SG_TRY(srcgan_nhwc_to_nchw_f32(w8 + last.off, y_nchw, B, P.out_ch, last.H, last.W, last.cs, 0, dt, st));
     return 0;
 }
 
-extern "C" int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
-                                         float* const* grads, void* st) {
-    RdPlan P;
-    SG_TRY(rd_plan(c, P));
-    SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "srcgan_resdeconv_backward: null pointer");
-    SG_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)scratch % 256) == 0, "srcgan_resdeconv_backward: buffers must be 256-byte aligned");
-    const int dt = c->dtype, B = c->B;
+static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const* params, void* ws, void* scratch, float* const* grads,
+                       const char* tag, void* st) {
+    SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "%s backward: null pointer", tag);
+    SG_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)scratch % 256) == 0, "%s backward: buffers must be 256-byte aligned", tag);
+    const int dt = P.dtype, B = P.B;
     char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
-    float* slab = (float*)(s8 + P.slab); float* gnscr = (float*)(s8 + P.gnscr);
-    auto G = [&](int idx) { return grads[idx]; };
-    // dgrad weight packs
-    {
+    float* slab = (float*)(s8 + P.slab); float* gnscr = (float*)(s8 + P.gnscr); float* colscr = (float*)(s8 + P.colscr);
+    auto G = [&](int idx) { return idx >= 0 ? grads[idx] : nullptr; };
+    {   // dgrad weight packs
         PackList packs(dt, wp);
         for (const RdOp& o : P.ops) {
             const RdT ti = P.T[o.in], to = P.T[o.out];
@@ -1017,32 +1074,39 @@ extern "C" int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const fl
                 packs.add(params[o.w], wp + o.wd[0], ti.C, to.C, 2, 2, (long)to.C * 4, 4, 2, 1, 0);
             }
         }
-        SG_TRY(packs.run("resdeconv_bwd", params[0], st));
+        char key[64]; snprintf(key, sizeof(key), "%s_bwd", tag);
+        SG_TRY(packs.run(key, params[0], st));
     }
     std::vector<char> written(P.T.size(), 0);
     auto gt = [&](int id) { return tref(s8 + P.g[id], P.T[id].cs); };
     {
         const RdT& last = P.T.back();
         const int id = (int)P.T.size() - 1;
-        SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, s8 + P.g[id], B, c->out_ch, last.H, last.W, last.cs, dt, st));
+        SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, s8 + P.g[id], B, P.out_ch, last.H, last.W, last.cs, dt, st));
+        if (last.act) SG_TRY(srcgan_mask_inplace(s8 + P.g[id], w8 + last.off, 0.f, (long)B * last.H * last.W * last.cs, dt, st));
         written[id] = 1;
     }
     for (int k = (int)P.ops.size() - 1; k >= 0; --k) {
         const RdOp& o = P.ops[k];
         const RdT ti = P.T[o.in], to = P.T[o.out];
-        SG_REQUIRE(written[o.out], "resdeconv backward: internal error (gradient of tensor %d missing)", o.out);
+        SG_REQUIRE(written[o.out], "%s backward: internal error (gradient of tensor %d missing)", tag, o.out);
         TRef xin = rd_t(w8, ti), dy = gt(o.out);
         const bool need_dx = o.in != 0;
         TRef dx = need_dx ? gt(o.in) : TNULL;
         const bool acc = need_dx && written[o.in];
         if (o.type == 0) {
+            const bool fused_bias = o.bias >= 0 && o.k == 3 && G(o.w);
             if (G(o.w))
-                SG_TRY(wgrad_call(dt, dy, to.H, to.W, to.C, xin, B, ti.H, ti.W, ti.C, o.k, o.k, o.s, o.pad, o.pad, lay_fwd(ti.C, o.k, o.k), 1.f, slab, G(o.w), st));
+                SG_TRY(wgrad_call(dt, dy, to.H, to.W, to.C, xin, B, ti.H, ti.W, ti.C, o.k, o.k, o.s, o.pad, o.pad, lay_fwd(ti.C, o.k, o.k), 1.f, slab, G(o.w), st,
+                                  fused_bias ? G(o.bias) : nullptr));
+            if (o.bias >= 0 && G(o.bias) && !fused_bias) SG_TRY(bias_grad(dt, dy, (long)B * to.H * to.W, to.C, 1.f, G(o.bias), colscr, st));
             if (need_dx) {
+                SG_REQUIRE(!(acc && ti.act), "%s backward: internal error (activated tensor with two consumers)", tag);
                 if (o.s == 1) {
                     Conv cv(dt, o.k, o.k, 1);
                     cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad);
                     if (acc) cv.res1(dx, ti.C, 1.f);
+                    if (ti.act) { cv.mask(xin, 0); cv.d.mslope = 0.f; }
                     SG_TRY(cv.run(st));
                 } else if (o.k == 1) {
                     if (!acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * P.esz, (hipStream_t)st));
@@ -1064,23 +1128,56 @@ extern "C" int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const fl
             }
         } else if (o.type == 1) {
             void* dres = nullptr; int dres_cs = 0;
-            if (o.res >= 0) {
-                // the residual branch's gradient: plain store when it is the tensor's first contribution, else through a temporary is
-                // never needed here (a block input always meets its shortcut first in this reverse walk)
-                SG_REQUIRE(!written[o.res], "resdeconv backward: internal error (residual gradient order)");
+            if (o.res >= 0) {       // a block input always meets its shortcut first in this reverse walk: plain store
+                SG_REQUIRE(!written[o.res], "%s backward: internal error (residual gradient order)", tag);
                 dres = s8 + P.g[o.res]; dres_cs = P.T[o.res].cs; written[o.res] = 1;
             }
-            SG_REQUIRE(!acc, "resdeconv backward: internal error (GroupNorm input has two consumers)");
+            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (GroupNorm input has two consumers or a fused activation)", tag);
             SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, params[o.w], (const float*)(w8 + o.stats),
                                       dx.p, ti.cs, dres, dres_cs, G(o.w), G(o.w + 1), 0, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
             written[o.in] = 1;
-        } else {
+        } else if (o.type == 2) {
             if (G(o.w))     // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2
                 SG_TRY(wgrad_call(dt, xin, ti.H, ti.W, ti.C, dy, B, to.H, to.W, to.C, 2, 2, 2, 0, 0, WLayout{(long)to.C * 4, 4, 2, 1, 0}, 1.f, slab, G(o.w), st));
-            SG_REQUIRE(!acc, "resdeconv backward: internal error (deconvolution input has two consumers)");
+            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (deconvolution input)", tag);
             SG_TRY(Conv(dt, 2, 2, 2).in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(0, 0).run(st));
+            written[o.in] = 1;
+        } else {
+            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (PixelShuffle input)", tag);
+            SG_TRY(srcgan_pixel_shuffle_nhwc(dy.p, to.cs, dx.p, ti.cs, B, ti.H, ti.W, to.C, o.k, 1, dt, st));
             written[o.in] = 1;
         }
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int srcgan_resdeconv_num_params(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return -1; return P.nparams; }
+extern "C" size_t srcgan_resdeconv_ws_bytes(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return 0; return P.total; }
+extern "C" size_t srcgan_resdeconv_bwd_scratch_bytes(const srcgan_resdeconv_cfg* c) { RdPlan P; if (rd_plan(c, P)) return 0; return P.bwd_total; }
+extern "C" int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* st) {
+    RdPlan P;
+    SG_TRY(rd_plan(c, P));
+    return rd_forward(P, x_nchw, params, ws, y_nchw, "resdeconv", st);
+}
+extern "C" int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
+                                         float* const* grads, void* st) {
+    RdPlan P;
+    SG_TRY(rd_plan(c, P));
+    return rd_backward(P, dy_nchw, params, ws, scratch, grads, "resdeconv", st);
+}
+
+extern "C" int srcgan_srnet_num_params(const srcgan_srnet_cfg* c) { RdPlan P; if (sr_plan(c, P)) return -1; return P.nparams; }
+extern "C" size_t srcgan_srnet_ws_bytes(const srcgan_srnet_cfg* c) { RdPlan P; if (sr_plan(c, P)) return 0; return P.total; }
+extern "C" size_t srcgan_srnet_bwd_scratch_bytes(const srcgan_srnet_cfg* c) { RdPlan P; if (sr_plan(c, P)) return 0; return P.bwd_total; }
+extern "C" int srcgan_srnet_forward(const srcgan_srnet_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* st) {
+    RdPlan P;
+    SG_TRY(sr_plan(c, P));
+    return rd_forward(P, x_nchw, params, ws, y_nchw, c->kind == 0 ? "espcn" : "srcnn", st);
+}
+extern "C" int srcgan_srnet_backward(const srcgan_srnet_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
+                                     float* const* grads, void* st) {
+    RdPlan P;
+    SG_TRY(sr_plan(c, P));
+    return rd_backward(P, dy_nchw, params, ws, scratch, grads, c->kind == 0 ? "espcn" : "srcnn", st);
 }

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _native as N
 
-__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
+__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "ESPCN", "SRCNN", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
            "get_deconv_params"]
 
 
@@ -381,6 +381,100 @@ class ResDeconv(nn.Module):
         if self.src_ch == 1:
             x = torch.cat([x, x, x], dim=1)
         return _ResDeconvFn.apply(x, self.tar_ch, N.dtype_id(self.compute_dtype), *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
+
+
+# ------------------------------------------------------------------------------------------------ ESPCN / SRCNN
+class _SrNetFn(torch.autograd.Function):
+    """One native forward / backward for the small --SRModel networks (kind 0 ESPCN, 1 SRCNN)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg_items, *params):
+        N.require_cuda(x, "ESPCN/SRCNN forward")
+        lib = N.lib()
+        kind, in_ch, out_ch, up, base, dtype = cfg_items
+        if x.dim() != 4 or x.shape[1] != in_ch:
+            raise ValueError(f"expected [B,{in_ch},H,W], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, _, H, W = x.shape
+        cfg = N.SrNetCfg(kind, in_ch, out_ch, up, base, B, H, W, dtype)
+        for p in params:
+            N.require_cuda(p, "parameter")
+        plist = [p.detach().contiguous() for p in params]
+        ws = N.workspace(lib.srcgan_srnet_ws_bytes(C.byref(cfg)), x.device)
+        f = up if kind == 0 else 1
+        y = torch.empty(B, out_ch, H * f, W * f, dtype=torch.float32, device=x.device)
+        N.check(lib.srcgan_srnet_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(), N.stream_ptr(x.device)),
+                "srcgan_srnet_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(*plist)
+        ctx.hook = _grad_hooks.get("srnet")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = N.lib()
+        params = list(ctx.saved_tensors)
+        cfg = ctx.cfg
+        if ctx.ws is None:
+            raise RuntimeError("backward called twice (activations were released)")
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("ESPCN/SRCNN: no gradient w.r.t. the input (the reference harness feeds data, trainCas.py:89-91)")
+        dy = dy.contiguous().float()
+        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(params)]
+        scratch = N.workspace(lib.srcgan_srnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
+        N.check(lib.srcgan_srnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
+                                          N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_srnet_backward")
+        ctx.ws = None
+        if ctx.hook is not None:
+            ctx.hook(grads)
+        return (None, None, *grads)
+
+
+class ESPCN(nn.Module):
+    """Drop-in for reference ``model.ESPCN`` (src/model/espcn.py:18-51; the CLI default ``--SRModel``, trainCas.py:169):
+    5x5, 3x3, 3x3 convolutions + ReLU, 3x3 to 64 r^2 channels, PixelShuffle(r), 3x3."""
+
+    def __init__(self, in_ch=3, ou_ch=3, upscale_factor=2, base_kernel=64, dtype=None):
+        super().__init__()
+        kernels = [int(x * base_kernel) for x in [1, 1, 1 / 2]]
+        self.relu = nn.ReLU(True)
+        self.conv1 = nn.Conv2d(in_ch, kernels[0], kernel_size=5, stride=1, padding=2)
+        self.conv2 = nn.Conv2d(kernels[0], kernels[1], kernel_size=3, stride=1, padding=1)
+        self.conv3 = nn.Conv2d(kernels[1], kernels[2], kernel_size=3, stride=1, padding=1)
+        self.conv4 = nn.Conv2d(kernels[2], base_kernel * upscale_factor ** 2, kernel_size=3, stride=1, padding=1)
+        self.pixel_shuffle = nn.PixelShuffle(upscale_factor)
+        self.conv5 = nn.Conv2d(base_kernel, ou_ch, kernel_size=3, stride=1, padding=1)
+        _kaiming_like_reference(self)
+        self._cfg = (0, in_ch, ou_ch, upscale_factor, base_kernel)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, x):
+        return _SrNetFn.apply(x, (*self._cfg, N.dtype_id(self.compute_dtype)), *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
+
+
+class SRCNN(nn.Module):
+    """Drop-in for reference ``model.SRCNN`` (src/model/srcnn.py:17-42): 9x9, 1x1, 5x5 convolutions, each followed by ReLU;
+    the output has the input's size (``upscale_factor`` is stored and unused, as in the reference); torch default init."""
+
+    def __init__(self, in_ch=3, ou_ch=3, upscale_factor=2, base_kernel=64, dtype=None):
+        super().__init__()
+        kernels = [int(x * base_kernel) for x in [1, 1 / 2]]
+        self.up = upscale_factor
+        self.relu = nn.ReLU(True)
+        self.conv1 = nn.Conv2d(in_ch, kernels[0], kernel_size=9, stride=1, padding=4)
+        self.conv2 = nn.Conv2d(kernels[0], kernels[1], kernel_size=1, stride=1, padding=0)
+        self.conv3 = nn.Conv2d(kernels[1], ou_ch, kernel_size=5, stride=1, padding=2)
+        self._cfg = (1, in_ch, ou_ch, upscale_factor, base_kernel)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, x):
+        return _SrNetFn.apply(x, (*self._cfg, N.dtype_id(self.compute_dtype)), *self.parameters())
 
     def extra_repr(self):
         return f"native gfx950, compute_dtype={self.compute_dtype}"

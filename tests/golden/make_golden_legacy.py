@@ -46,5 +46,45 @@ def main():
         print(tag, tuple(y.shape), float(loss), "params without grad:", len(nograd))
 
 
+def small_sr():
+    """ESPCN (the CLI default --SRModel, trainCas.py:169) and SRCNN, reference src/model/{espcn,srcnn}.py."""
+    from model import ESPCN, SRCNN
+    for tag, cls, args, shape, up in (("espcn_x2", ESPCN, (1, 1, 2), (2, 1, 20, 28), 2), ("espcn_x3", ESPCN, (3, 3, 3), (1, 3, 12, 10), 3),
+                                      ("srcnn", SRCNN, (3, 3, 2), (2, 3, 18, 22), 1)):
+        torch.manual_seed(0)
+        m = cls(*args)
+        x = torch.rand(*shape, requires_grad=False)
+        t = torch.rand(shape[0], args[1], shape[2] * up, shape[3] * up)
+        y = m(x)
+        loss = nn.L1Loss()(y, t)
+        loss.backward()
+        np.savez(os.path.join(OUT, f"{tag}.npz"), cfg=np.array(args), x=npy(x), t=npy(t), y=npy(y), loss=npy(loss), **sd_np(m),
+                 **{"grad/" + k: npy(p.grad) for k, p in m.named_parameters()})
+        print(tag, tuple(y.shape), float(loss))
+
+
+def cas_default():
+    """Two CasSRC.optimize_parameters steps in the reference's DEFAULT configuration (trainCas.py:169-171: --SRModel ESPCN,
+    --CModel ResDeconv, --up 2): losses and PSNRs only -- the build reproduces both networks' seeded initial weights."""
+    import trainCas
+
+    class Opt:
+        device = torch.device("cpu"); lr = 1e-4; batch_size = 1; num_works = 0
+        num_epochs = 50; matrix = 0; lr_policy = "cosine"; up = 2
+        SRModel = "ESPCN"; CModel = "ResDeconv"
+    torch.manual_seed(0)
+    cas = trainCas.CasSRC(Opt)
+    cas.init_log()
+    realA = torch.rand(2, 1, 64, 96)
+    realB = torch.rand(2, 3, 64, 96)
+    for _ in range(2):
+        cas.optimize_parameters(realA, realB)
+    np.savez(os.path.join(OUT, "cas_default.npz"), realA=npy(realA), realB=npy(realB), loss_sr=np.array(cas.loss_sr), loss_c=np.array(cas.loss_c),
+             psnr_sr=np.array(cas.psnr_sr), psnr_c=np.array(cas.psnr_c), fake_AB=npy(cas.fake_AB), fake_BC=npy(cas.fake_BC))
+    print("cas_default", cas.loss_sr, cas.loss_c, cas.psnr_sr, cas.psnr_c)
+
+
 if __name__ == "__main__":
     main()
+    small_sr()
+    cas_default()

@@ -77,4 +77,4 @@ def test_bad_arguments_are_rejected_before_launch(ops):
     with pytest.raises(RuntimeError, match="multiples of 8"):
         ops.conv_igemm(x, wp, y, kh=3, kw=3, Cout=8, pad=(1, 1))
     with pytest.raises(RuntimeError, match="unsupported kernel"):
-        ops.conv_igemm(torch.zeros(1, 4, 4, 8, device="cuda", dtype=torch.bfloat16), wp, y, kh=5, kw=5, Cout=8, pad=(2, 2))
+        ops.conv_igemm(torch.zeros(1, 4, 4, 8, device="cuda", dtype=torch.bfloat16), wp, y, kh=6, kw=6, Cout=8, pad=(2, 2))

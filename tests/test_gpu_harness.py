@@ -1,6 +1,8 @@
 """GPU: the step harnesses (reference call sequences) against the oracle / reference golden vectors, f32 mode."""
 import random
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -174,3 +176,28 @@ def test_fused_adam_matches_torch_adam():
     before = q[0].detach().clone()
     o.step()
     assert type(o) is Adam and not torch.equal(before, q[0])
+
+
+def test_cas_default_configuration_golden():
+    """The reference's default cascade (trainCas.py:169-171: ESPCN + ResDeconv, up 2), two optimisation steps: both native
+    networks start from the reference's seeded weights; every logged loss / PSNR and the final outputs must match."""
+    from srcgan_amd import train as T
+    g = load_golden("cas_default")
+    opt = T.CasParams(device="cuda", SRModel="ESPCN", CModel="ResDeconv", up=2)
+    torch.manual_seed(0)
+    m = T.CasSRC(opt)
+    realA, realB = torch.from_numpy(g["realA"]).cuda(), torch.from_numpy(g["realB"]).cuda()
+    for _ in range(2):
+        m.optimize_parameters(realA, realB)
+    for mine, ref in ((m.loss_sr, g["loss_sr"]), (m.loss_c, g["loss_c"])):
+        assert np.allclose([float(v) for v in mine], ref, rtol=1e-3, atol=1e-6), (mine, ref)
+    for mine, ref in ((m.psnr_sr, g["psnr_sr"]), (m.psnr_c, g["psnr_c"])):
+        assert np.allclose([float(v) for v in mine], ref, rtol=0, atol=2e-3), (mine, ref)
+    assert rel_err(m.fake_BC.cpu(), g["fake_BC"]) < 2e-3
+    # colouriser output after two Adam steps from the reference's start.  GroupNorm bias gradients are sums over all pixels with
+    # heavy cancellation; where such a sum is at rounding level its SIGN depends on the accumulation order, and Adam's first
+    # updates are +-lr whatever the magnitude (scripts/diag_cas_default.py: those biases differ by exactly lr = 1e-4 from the CPU
+    # run, every loss still agrees to 1e-5).  Hence relative L2 with a 5 % bound here; fp32 forward/backward parity is pinned by
+    # the per-network golden tests.
+    from conftest import rel_l2
+    assert rel_l2(m.fake_AB.cpu(), torch.from_numpy(g["fake_AB"])) < 5e-2

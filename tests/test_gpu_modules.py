@@ -294,3 +294,34 @@ def test_resdeconv_bf16_vs_oracle():
         if k.startswith(("pred", "deconv13", "upRes3.1")):
             assert rel_l2(p.grad.cpu(), sd[k].grad) < 5e-2, k
         assert cos(p.grad.cpu(), sd[k].grad) > 0.75, (k, cos(p.grad.cpu(), sd[k].grad))
+
+
+@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn"])
+def test_small_sr_models_golden_f32(tag):
+    """Native ESPCN (the reference's default --SRModel) and SRCNN against reference outputs, losses and every parameter gradient."""
+    from srcgan_amd import ESPCN, SRCNN, L1Loss
+    g = load_golden(tag)
+    ic, oc, up = [int(v) for v in g["cfg"]]
+    net = _load((SRCNN if tag == "srcnn" else ESPCN)(ic, oc, up, dtype="fp32"), sub(g, "sd/"))
+    y = net(torch.from_numpy(g["x"]).cuda())
+    assert rel_err(y.cpu(), g["y"]) < F32_TOL
+    loss = L1Loss()(y, torch.from_numpy(g["t"]).cuda())
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    grads = sub(g, "grad/")
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+
+
+def test_espcn_bf16_vs_oracle():
+    from srcgan_amd import ESPCN, MSELoss
+    torch.manual_seed(6)
+    net = ESPCN(1, 1, 2, dtype="bf16").cuda()
+    sd = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in net.named_parameters()}
+    x, t = torch.rand(2, 1, 40, 56), torch.rand(2, 1, 80, 112)
+    yr = oracle.espcn_forward(sd, x, 2)
+    oracle.mse_loss(yr, t).backward()
+    y = net(x.cuda())
+    MSELoss()(y, t.cuda()).backward()
+    assert rel_l2(y.cpu(), yr) < 3e-2
+    assert max(rel_l2(p.grad.cpu(), sd[k].grad) for k, p in net.named_parameters()) < 6e-2

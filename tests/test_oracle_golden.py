@@ -224,3 +224,27 @@ def test_resdeconv(tag):
         assert abs(mine[1] - ref[1]) <= 1e-3 * max(ref[1], 1e-12), k
     for k, v in sub(g, "grad/").items():
         assert rel_err(sd[k].grad, v) < 1e-4, k
+
+
+@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn"])
+def test_small_sr_models(tag):
+    """ESPCN (espcn.py; the CLI default --SRModel) and SRCNN (srcnn.py) restatements against reference outputs / gradients,
+    and the seeded holders of the package against the reference's initial weights."""
+    import srcgan_amd
+    g = load_golden(tag)
+    ic, oc, up = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    sd = _req(ref)
+    x = torch.from_numpy(g["x"])
+    y = oracle.srcnn_forward(sd, x) if tag == "srcnn" else oracle.espcn_forward(sd, x, up)
+    loss = oracle.l1_loss(y, torch.from_numpy(g["t"]))
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < TOL, k
+    torch.manual_seed(0)
+    net = (srcgan_amd.SRCNN if tag == "srcnn" else srcgan_amd.ESPCN)(ic, oc, up)
+    assert list(net.state_dict().keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert torch.equal(net.state_dict()[k], v), k
