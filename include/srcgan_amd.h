@@ -305,6 +305,15 @@ int srcgan_pixel_shuffle_nhwc(const void* src, int s_cs, void* dst, int d_cs, in
                               int dtype, void* stream);
 int srcgan_mask_inplace(void* g, const void* act, float slope, long n, int dtype, void* stream);
 
+/* Evaluation metrics on device (metrics.py:10-144; test loop testCas.py:65-90).  pred / truth: [B,C,H,W] f32 NCHW.
+ *   srcgan_metric_ae:   out[b] = mean over pixels of acos(<p,t>/(|p||t| + 1e-6)) in degrees
+ *   srcgan_metric_ssim: out[b][0] = mean SSIM (11x11 gaussian sigma 1.5 "valid" windows, dynamic range from the prediction's
+ *                       min / max as metrics.py:100-107), out[b][1] = mean contrast term
+ * MSE / PSNR: srcgan_loss_fwd(kind 1) + srcgan_psnr_from_mse.  scratch: srcgan_metric_scratch_floats(B, C, H, W) floats. */
+int srcgan_metric_scratch_floats(int B, int C, int H, int W);
+int srcgan_metric_ae(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
+int srcgan_metric_ssim(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
+
 /* Fused multi-tensor Adam (torch.optim.Adam.step() of trainCas.py:38-41,143-150 / train.py:191-192,331-340; torch's
  * single-tensor arithmetic, default flags: no weight decay, no amsgrad).  tensors_dev: device array of records
  * {float* p; const float* g; float* m; float* v;} (32 bytes); chunks_dev: device array of nchunks records

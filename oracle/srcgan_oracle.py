@@ -32,7 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
-    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "metric_ae", "metric_ssim",
 ]
 
 
@@ -176,6 +176,39 @@ def srcnn_forward(sd: State, x: Tensor) -> Tensor:
     """SRCNN.forward, srcnn.py:38-42 (ReLU after every convolution, the last included)."""
     c = lambda n, t: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], 1, sd[n + ".weight"].shape[-1] // 2)
     return F.relu(c("conv3", F.relu(c("conv2", F.relu(c("conv1", x))))))
+
+
+# ---------------------------------------------------------------------------
+# Evaluation metrics  (reference src/metrics.py:10-144)
+# ---------------------------------------------------------------------------
+
+def metric_ae(y_pred: Tensor, y_true: Tensor) -> Tensor:
+    """AE.__call__, metrics.py:22-33: per-image mean angular error in degrees."""
+    dot = torch.sum(y_pred * y_true, dim=1)
+    n1 = torch.sqrt(torch.sum(y_pred * y_pred, dim=1))
+    n2 = torch.sqrt(torch.sum(y_true * y_true, dim=1))
+    return (180 / math.pi * torch.acos(dot / (n1 * n2 + 1e-6))).mean(1).mean(1)
+
+
+def metric_ssim(y_pred: Tensor, y_true: Tensor, size_average: bool = True, full: bool = False):
+    """SSIM.__call__, metrics.py:85-144 (w_size 11, sigma 1.5, valid depth-wise windows, range from the prediction)."""
+    max_val = 255 if torch.max(y_pred) > 128 else 1
+    min_val = -1 if torch.min(y_pred) < -0.5 else 0
+    L = max_val - min_val
+    ch = y_pred.shape[1]
+    g = torch.Tensor([math.exp(-(x - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+    g = (g / g.sum()).unsqueeze(1)
+    window = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(ch, 1, 11, 11).contiguous()
+    conv = lambda z: F.conv2d(z, window, padding=0, groups=ch)
+    mu1, mu2 = conv(y_pred), conv(y_true)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = conv(y_pred * y_pred) - mu1_sq, conv(y_true * y_true) - mu2_sq, conv(y_pred * y_true) - mu12
+    C1, C2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    v1, v2 = 2.0 * s12 + C2, s1 + s2 + C2
+    cs = torch.mean(v1 / v2)
+    m = ((2 * mu12 + C1) * v1) / ((mu1_sq + mu2_sq + C1) * v2)
+    ret = m.mean() if size_average else m.mean(1).mean(1).mean(1)
+    return (ret, cs) if full else ret
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:

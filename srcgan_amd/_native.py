@@ -147,6 +147,9 @@ SIGNATURES = {
     "srcgan_srnet_backward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P, _P]),
     "srcgan_pixel_shuffle_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_mask_inplace": (_I, [_P, _P, _F, _L, _I, _P]),
+    "srcgan_metric_scratch_floats": (_I, [_I, _I, _I, _I]),
+    "srcgan_metric_ae": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "srcgan_metric_ssim": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "srcgan_adam_step": (_I, [_P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _L, _P]),
     "srcgan_prof_enable": (_I, [_I]),
     "srcgan_prof_collect": (_I, []),

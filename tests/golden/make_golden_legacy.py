@@ -84,7 +84,25 @@ def cas_default():
     print("cas_default", cas.loss_sr, cas.loss_c, cas.psnr_sr, cas.psnr_c)
 
 
+def metrics_golden():
+    """Reference src/metrics.py (AE, MSE, PSNR, SSIM) on three value ranges that select SSIM's three dynamic ranges."""
+    import metrics as ref
+    out = {}
+    for tag, scale, shift in (("unit", 1.0, 0.0), ("byte", 255.0, 0.0), ("signed", 2.0, -1.0)):
+        torch.manual_seed(7)
+        t = torch.rand(2, 3, 40, 52) * scale + shift
+        p = (t + 0.1 * scale * torch.randn(2, 3, 40, 52)).clamp(shift, shift + scale)
+        out[f"{tag}/pred"], out[f"{tag}/true"] = npy(p), npy(t)
+        out[f"{tag}/ae"] = npy(ref.AE()(p, t)); out[f"{tag}/mse"] = npy(ref.MSE()(p, t)); out[f"{tag}/psnr"] = npy(ref.PSNR()(p, t))
+        s, cs = ref.SSIM()(p, t, full=True)
+        out[f"{tag}/ssim"], out[f"{tag}/cs"] = npy(s), npy(cs)
+        out[f"{tag}/ssim_per_image"] = npy(ref.SSIM()(p, t, size_average=False))
+    np.savez(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics", {k: float(v) for k, v in out.items() if k.endswith(("/ssim", "/psnr"))})
+
+
 if __name__ == "__main__":
     main()
     small_sr()
     cas_default()
+    metrics_golden()

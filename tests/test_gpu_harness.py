@@ -201,3 +201,29 @@ def test_cas_default_configuration_golden():
     # the per-network golden tests.
     from conftest import rel_l2
     assert rel_l2(m.fake_AB.cpu(), torch.from_numpy(g["fake_AB"])) < 5e-2
+
+
+@pytest.mark.parametrize("tag", ["unit", "byte", "signed"])
+def test_device_metrics_golden(tag):
+    """srcgan_amd.metrics (AE / MSE / PSNR / SSIM kernels) against values computed by the reference's src/metrics.py classes."""
+    from srcgan_amd import metrics as M
+    g = load_golden("metrics")
+    p, t = torch.from_numpy(g[f"{tag}/pred"]).cuda(), torch.from_numpy(g[f"{tag}/true"]).cuda()
+    assert rel_err(M.AE()(p, t).cpu(), g[f"{tag}/ae"]) < 1e-4
+    assert rel_err(M.MSE()(p, t).cpu(), g[f"{tag}/mse"]) < 1e-5
+    assert abs(float(M.PSNR()(p, t)) - float(g[f"{tag}/psnr"])) < 1e-3
+    s, cs = M.SSIM()(p, t, full=True)
+    assert abs(float(s) - float(g[f"{tag}/ssim"])) < 2e-5 and abs(float(cs) - float(g[f"{tag}/cs"])) < 2e-5
+    assert rel_err(M.SSIM()(p, t, size_average=False).cpu(), g[f"{tag}/ssim_per_image"]) < 1e-4
+    assert [repr(m) for m in (M.MSE(), M.PSNR(), M.AE(), M.SSIM())] == ["MSE", "PSNR", "AE", "SSIM"]
+
+
+def test_evaluate_cascade_loop():
+    """the testCas.py:65-90 scoring loop on native networks: finite metrics, the reference's output sizes."""
+    from srcgan_amd import ESPCN, ResDeconv, metrics as M
+    torch.manual_seed(1)
+    sr, cn = ESPCN(1, 1, 2).cuda(), ResDeconv(1, 3).cuda()
+    batches = [{"src": torch.rand(1, 1, 64, 64), "tar": torch.rand(1, 3, 64, 64)} for _ in range(2)]
+    perf, (fake_AB, fake_BB) = M.evaluate_cascade(sr, cn, batches, up=2)
+    assert set(perf) == {"MSE", "PSNR", "AE", "SSIM"} and all(np.isfinite(v) for v in perf.values())
+    assert fake_AB.shape == fake_BB.shape == (1, 3, 64, 64)

@@ -248,3 +248,16 @@ def test_small_sr_models(tag):
     assert list(net.state_dict().keys()) == list(ref.keys())
     for k, v in ref.items():
         assert torch.equal(net.state_dict()[k], v), k
+
+
+@pytest.mark.parametrize("tag", ["unit", "byte", "signed"])
+def test_metrics(tag):
+    """oracle restatements of src/metrics.py against values computed by the reference classes (three SSIM dynamic ranges)."""
+    g = load_golden("metrics")
+    p, t = torch.from_numpy(g[f"{tag}/pred"]), torch.from_numpy(g[f"{tag}/true"])
+    assert rel_err(oracle.metric_ae(p, t), g[f"{tag}/ae"]) < 1e-6
+    assert rel_err(oracle.mse_loss(p, t), g[f"{tag}/mse"]) < 1e-6
+    assert abs(float(oracle.psnr(p, t)) - float(g[f"{tag}/psnr"])) < 1e-4
+    s, cs = oracle.metric_ssim(p, t, full=True)
+    assert abs(float(s) - float(g[f"{tag}/ssim"])) < 1e-6 and abs(float(cs) - float(g[f"{tag}/cs"])) < 1e-6
+    assert rel_err(oracle.metric_ssim(p, t, size_average=False), g[f"{tag}/ssim_per_image"]) < 1e-6
