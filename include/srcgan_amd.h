@@ -182,16 +182,18 @@ int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const
                               int dtype, void* stream);
 
 /* GroupNorm (+ residual add + ReLU) on NHWC activations (resdeconv.py:61-97,118-121; nn.GroupNorm(G, C), affine, biased
- * variance): y = relu?((x - mean[b][g]) * rstd[b][g] * gamma[c] + beta[c] [+ res]).  stats: device f32 [B][G][2] = {mean, rstd}
+ * variance): y = act?((x - mean[b][g]) * rstd[b][g] * gamma[c] + beta[c] [+ res]), act = (Leaky)ReLU with `slope` (0 = ReLU;
+ * edsr.py:43-49 uses 0.2) when relu != 0.  stats: device f32 [B][G][2] = {mean, rstd}
  * (written by forward, read by backward).  backward: g = dy [* (yact > 0)] (yact = the forward output when ReLU was applied);
- * dx = GroupNorm backward of g; dres (optional) = g (gradient of the residual branch); dgamma / dbeta (optional) f32 [C].
+ * dx = GroupNorm backward of g; dres (optional) = g (gradient of the residual branch; += when dres_accumulate); dgamma / dbeta
+ * (optional) f32 [C], += when accumulate (a GroupNorm module applied twice, edsr.py:41,47,49).
  * scratch: srcgan_gn_scratch_floats(B, C) floats.  C/epp must divide 256 (epp = 16 bytes of channels). */
 size_t srcgan_gn_scratch_floats(int B, int C);
 int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void* y, int y_cs, const float* gamma, const float* beta,
-                      float* stats, int B, long hw, int C, int G, float eps, int relu, int dtype, float* scratch, void* stream);
+                      float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream);
 int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
-                       void* dx, int dx_cs, void* dres, int dres_cs, float* dgamma, float* dbeta, int accumulate,
-                       int B, long hw, int C, int G, int dtype, float* scratch, void* stream);
+                       void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
+                       float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream);
 
 /* x2 nearest up-sampling of an NHWC feature map (src may be a channel slice of a blocked buffer: s_plane != 0) and its
  * adjoint: dst[y][x] = sum of the 2x2 block of src, times LeakyReLU'(mz[y][x]) when mz is given.  Replaces
@@ -284,13 +286,14 @@ int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw,
 int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws,
                               void* scratch, float* const* grads, void* stream);
 
-/* Small SR networks selectable as --SRModel (trainCas.py:169): kind 0 = ESPCN (espcn.py:18-51; the CLI default), kind 1 = SRCNN
- * (srcnn.py:17-42).  [B,in_ch,H,W] f32 NCHW -> ESPCN [B,out_ch,H*up,W*up] / SRCNN [B,out_ch,H,W].  params/grads in state_dict
+/* SR networks selectable as --SRModel (trainCas.py:169): kind 0 = ESPCN (espcn.py:18-51; the CLI default), kind 1 = SRCNN
+ * (srcnn.py:17-42), kind 2 = EDSR (edsr.py:37-110: GroupNorm residual blocks, [B,out_ch,H*up,W*up]).  [B,in_ch,H,W] f32 NCHW -> ESPCN [B,out_ch,H*up,W*up] / SRCNN [B,out_ch,H,W].  params/grads in state_dict
  * order (conv1.weight, conv1.bias, ...).  No gradient w.r.t. the input. */
 typedef struct srcgan_srnet_cfg {
-    int kind, in_ch, out_ch, up, base;     /* base = base_kernel (64) */
+    int kind, in_ch, out_ch, up, base;     /* base = base_kernel / base_channel (64) */
     int B, H, W;
     int dtype;
+    int nres;                              /* EDSR: num_residuals (50) */
 } srcgan_srnet_cfg;
 int srcgan_srnet_num_params(const srcgan_srnet_cfg* c);
 size_t srcgan_srnet_ws_bytes(const srcgan_srnet_cfg* c);

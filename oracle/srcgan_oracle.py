@@ -32,7 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
-    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "metric_ae", "metric_ssim",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "edsr_forward", "metric_ae", "metric_ssim",
 ]
 
 
@@ -209,6 +209,25 @@ def metric_ssim(y_pred: Tensor, y_true: Tensor, size_average: bool = True, full:
     m = ((2 * mu12 + C1) * v1) / ((mu1_sq + mu2_sq + C1) * v2)
     ret = m.mean() if size_average else m.mean(1).mean(1).mean(1)
     return (ret, cs) if full else ret
+
+
+def edsr_forward(sd: State, x: Tensor) -> Tensor:
+    """EDSR.forward, edsr.py:101-110; ResnetBlock.forward :44-50 (one GroupNorm module applied twice, LeakyReLU 0.2)."""
+    c = lambda n, t: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], 1, 1)
+    t = c("input_conv", x)
+    residual = t
+    i = 0
+    while f"residual_layers.{i}.conv1.weight" in sd:
+        pre = f"residual_layers.{i}."
+        gn = lambda z: F.group_norm(z, 32, sd[pre + "gn.weight"], sd[pre + "gn.bias"], 1e-5)
+        t = gn(c(pre + "conv2", _lrelu(gn(c(pre + "conv1", t))))) + t
+        i += 1
+    t = c("mid_conv", t) + residual
+    j = 0
+    while f"upscale_layers.{j}.weight" in sd:
+        t = F.conv_transpose2d(t, sd[f"upscale_layers.{j}.weight"], None, 2, 0)
+        j += 1
+    return c("output_conv", t)
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:

@@ -89,7 +89,7 @@ class ResDeconvCfg(C.Structure):
 
 
 class SrNetCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("kind", "in_ch", "out_ch", "up", "base", "B", "H", "W", "dtype")]
+    _fields_ = [(n, C.c_int) for n in ("kind", "in_ch", "out_ch", "up", "base", "B", "H", "W", "dtype", "nres")]
 
 
 class NLayerDCfg(C.Structure):
@@ -124,8 +124,8 @@ SIGNATURES = {
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
     "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
     "srcgan_gn_scratch_floats": (_S, [_I, _I]),
-    "srcgan_gn_forward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _L, _I, _I, _F, _I, _I, _P, _P]),
-    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _I, _I, _P, _P]),
+    "srcgan_gn_forward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _L, _I, _I, _F, _I, _F, _I, _P, _P]),
+    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _L, _I, _I, _I, _P, _P]),
     "srcgan_upsample2_nhwc": (_I, [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_sum2x2_nhwc": (_I, [_P, _I, _P, _I, _P, _I, _F, _I, _I, _I, _I, _I, _P]),
     "srcgan_loss_scratch_floats": (_I, []),

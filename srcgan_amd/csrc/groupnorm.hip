@@ -32,7 +32,7 @@ static inline int gn_nblk(long hw, int C, int epp) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int x_cs, const T* __restrict__ dy, int dy_cs,
                                                     const T* __restrict__ yact, int ya_cs, const float* __restrict__ stats,
-                                                    long hw, int C, int G, float* __restrict__ partial) {
+                                                    long hw, int C, int G, float slope, float* __restrict__ partial) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
     __shared__ float red[2][256 * EPP];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
 #pragma unroll
             for (int i = 0; i < EPP; ++i) {
                 float g = to_f(gv[i]);
-                if (yact && !(to_f(av[i]) > 0.f)) g = 0.f;
+                if (yact && !(to_f(av[i]) > 0.f)) g *= slope;
                 s0[i] += g; s1[i] += g * (to_f(xv[i]) - mu[i]) * rs[i];
             }
         }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gn_fold_k(const float* __restrict__ parti
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_k(const T* __restrict__ x, int x_cs, const T* __restrict__ res, int r_cs, T* __restrict__ y, int y_cs,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
-                                                  long hw, int C, int G, int relu, long nvec) {
+                                                  long hw, int C, int G, int relu, float slope, long nvec) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
     const int VG = C / EPP, cpg = C / G;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gn_apply_k(const T* __restrict__ x, int x
             const float mu = stats[(b * G + g) * 2], rs = stats[(b * G + g) * 2 + 1];
             float v = (to_f(xv[i]) - mu) * rs * gamma[c] + beta[c];
             if (res) v += to_f(rv[i]);
-            if (relu) v = v > 0.f ? v : 0.f;
+            if (relu) v = v > 0.f ? v : v * slope;
             o[i] = from_f<T>(v);
         }
         *(vecT*)(y + q * y_cs + c0) = o;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void gn_apply_k(const T* __restrict__ x, int x
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_k(const T* __restrict__ dy, int dy_cs, const T* __restrict__ yact, int ya_cs, const T* __restrict__ x, int x_cs,
                                                       const float* __restrict__ gamma, const float* __restrict__ stats, const float* __restrict__ gsum,
-                                                      T* __restrict__ dx, int dx_cs, T* __restrict__ dres, int dr_cs, long hw, int C, int G, long nvec) {
+                                                      T* __restrict__ dx, int dx_cs, T* __restrict__ dres, int dr_cs, int dres_acc, float slope, long hw, int C, int G, long nvec) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
     const int VG = C / EPP, cpg = C / G;
@@ -145,13 +145,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const T* __restrict__ dy, 
             const int c = c0 + i, g = c / cpg;
             const float mu = stats[(b * G + g) * 2], rs = stats[(b * G + g) * 2 + 1];
             float gg = to_f(gv[i]);
-            if (yact && !(to_f(av[i]) > 0.f)) gg = 0.f;
+            if (yact && !(to_f(av[i]) > 0.f)) gg *= slope;
             const float xh = (to_f(xv[i]) - mu) * rs;
             o[i] = from_f<T>(rs * (gg * gamma[c] - (gsum[(b * G + g) * 2] + xh * gsum[(b * G + g) * 2 + 1])));
             gm[i] = from_f<T>(gg);
         }
         *(vecT*)(dx + q * dx_cs + c0) = o;
-        if (dres) *(vecT*)(dres + q * dr_cs + c0) = gm;
+        if (dres) {
+            if (dres_acc) {
+                const vecT old = *(const vecT*)(dres + q * dr_cs + c0);
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) gm[i] = from_f<T>(to_f(gm[i]) + to_f(old[i]));
+            }
+            *(vecT*)(dres + q * dr_cs + c0) = gm;
+        }
     }
 }
 
@@ -177,7 +184,7 @@ static int gn_check(const char* who, int B, long hw, int C, int G, int dtype) {
 extern "C" size_t srcgan_gn_scratch_floats(int B, int C) { return (size_t)B * GN_MAXBLK * C * 2 + (size_t)B * C * 2 + (size_t)B * 1024 * 2; }
 
 extern "C" int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void* y, int y_cs, const float* gamma, const float* beta,
-                                 float* stats, int B, long hw, int C, int G, float eps, int relu, int dtype, float* scratch, void* stream) {
+                                 float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream) {
     SG_REQUIRE(x && y && gamma && beta && stats && scratch, "srcgan_gn_forward: null pointer");
     SG_TRY(gn_check("srcgan_gn_forward", B, hw, C, G, dtype));
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
@@ -186,17 +193,17 @@ extern "C" int srcgan_gn_forward(const void* x, int x_cs, const void* res, int r
     const int nblk = gn_nblk(hw, C, epp);
     const long nvec = (long)B * hw * (C / epp);
     DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((gn_partial_k<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, (const float*)nullptr, hw, C, G, scratch);
+        hipLaunchKernelGGL((gn_partial_k<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, (const float*)nullptr, hw, C, G, 0.f, scratch);
         hipLaunchKernelGGL(gn_fold_k<0>, dim3(B), dim3(256), 0, st, (const float*)scratch, nblk, C, G, hw, eps, (const float*)nullptr, stats, (float*)nullptr);
-        hipLaunchKernelGGL(gn_apply_k<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)x, x_cs, (const T*)res, res_cs, (T*)y, y_cs, gamma, beta, (const float*)stats, hw, C, G, relu, nvec);
+        hipLaunchKernelGGL(gn_apply_k<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)x, x_cs, (const T*)res, res_cs, (T*)y, y_cs, gamma, beta, (const float*)stats, hw, C, G, relu, slope, nvec);
     });
     SG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
-                                  void* dx, int dx_cs, void* dres, int dres_cs, float* dgamma, float* dbeta, int accumulate,
-                                  int B, long hw, int C, int G, int dtype, float* scratch, void* stream) {
+                                  void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
+                                  float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream) {
     SG_REQUIRE(dy && x && gamma && stats && dx && scratch, "srcgan_gn_backward: null pointer");
     SG_TRY(gn_check("srcgan_gn_backward", B, hw, C, G, dtype));
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
@@ -208,10 +215,10 @@ extern "C" int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, i
     float* chan = scratch + (size_t)B * GN_MAXBLK * C * 2;
     float* gsum = chan + (size_t)B * C * 2;
     DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((gn_partial_k<T, 1>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)yact, ya_cs, stats, hw, C, G, scratch);
+        hipLaunchKernelGGL((gn_partial_k<T, 1>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)yact, ya_cs, stats, hw, C, G, slope, scratch);
         hipLaunchKernelGGL(gn_fold_k<1>, dim3(B), dim3(256), 0, st, (const float*)scratch, nblk, C, G, hw, 0.f, gamma, gsum, chan);
         hipLaunchKernelGGL(gn_bwd_apply_k<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, dy_cs, (const T*)yact, ya_cs, (const T*)x, x_cs, gamma, stats,
-                           (const float*)gsum, (T*)dx, dx_cs, (T*)dres, dres_cs, hw, C, G, nvec);
+                           (const float*)gsum, (T*)dx, dx_cs, (T*)dres, dres_cs, dres_accumulate, slope, hw, C, G, nvec);
     });
     if (dgamma || dbeta) hipLaunchKernelGGL(gn_param_grad_k, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)chan, B, C, dgamma, dbeta, accumulate);
     SG_LAUNCH_CHECK();

@@ -847,6 +847,7 @@ struct RdOp {
     int type;                 // 0 conv (+bias)(+ReLU), 1 GroupNorm(+res)(+ReLU), 2 ConvTranspose2d k2 s2, 3 PixelShuffle(r)
     int in, out, res, relu;
     int k, s, pad, w, bias;   // w: parameter index of the weight (GroupNorm: gamma, beta = w + 1); bias: parameter index or -1
+    float slope;              // GroupNorm activation: 0 = ReLU, 0.2 = LeakyReLU (edsr.py:42)
     size_t wf[4], wd[4], stats;
 };
 struct RdPlan {
@@ -985,7 +986,8 @@ static int rd_plan(const srcgan_resdeconv_cfg* c, RdPlan& P) {
 static int sr_plan(const srcgan_srnet_cfg* c, RdPlan& P) {
     SG_REQUIRE(c, "srnet: null cfg");
     SG_TRY(rd_common(c->dtype, c->B, c->H, c->W, P, "srnet"));
-    SG_REQUIRE(c->kind == 0 || c->kind == 1, "srnet: kind must be 0 (ESPCN) or 1 (SRCNN)");
+    SG_REQUIRE(c->kind >= 0 && c->kind <= 2, "srnet: kind must be 0 (ESPCN), 1 (SRCNN) or 2 (EDSR)");
+    SG_REQUIRE(c->kind != 2 || (c->nres >= 1 && c->base % 32 == 0 && (c->up & (c->up - 1)) == 0), "srnet: EDSR needs num_residuals >= 1, base_channel % 32 == 0 and a power-of-two upscale factor");
     SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8 && c->out_ch > 0 && c->out_ch <= 8, "srnet: in/out channels must be in 1..8");
     SG_REQUIRE(c->base > 0 && c->base % 16 == 0, "srnet: base_kernel must be a multiple of 16");
     SG_REQUIRE(c->up >= 1 && c->up <= 8, "srnet: upscale_factor must be in 1..8");
@@ -998,10 +1000,32 @@ static int sr_plan(const srcgan_srnet_cfg* c, RdPlan& P) {
         t = nb.conv(t, c->base * c->up * c->up, 3, 1, 1, true, false);
         t = nb.shuffle(t, c->up);
         nb.conv(t, c->out_ch, 3, 1, 1, true, false);
-    } else {
+    } else if (c->kind == 1) {
         int t = nb.conv(0, c->base, 9, 1, 4, true, true);
         t = nb.conv(t, c->base / 2, 1, 1, 0, true, true);
         nb.conv(t, c->out_ch, 5, 1, 2, true, true);
+    } else {
+        // EDSR (edsr.py:37-110): input_conv; num_residuals x [conv1 -> gn -> LeakyReLU(0.2) -> conv2 -> gn (the SAME GroupNorm
+        // module) -> + x]; mid_conv + input_conv's output; ConvTranspose2d k2 s2 per x2 stage; output_conv.  state_dict order
+        // inside a block: conv1.{w,b}, conv2.{w,b}, gn.{w,b}.
+        const int feat = nb.conv(0, c->base, 3, 1, 1, true, false);
+        int t = feat;
+        for (int i = 0; i < c->nres; ++i) {
+            const int base = nb.np, x = t;
+            t = nb.conv(x, c->base, 3, 1, 1, true, false);
+            P.ops.back().w = base; P.ops.back().bias = base + 1;
+            t = nb.gn(t, -1, 1);
+            P.ops.back().w = base + 4; P.ops.back().slope = 0.2f;
+            t = nb.conv(t, c->base, 3, 1, 1, true, false);
+            P.ops.back().w = base + 2; P.ops.back().bias = base + 3;
+            t = nb.gn(t, x, 0);
+            P.ops.back().w = base + 4;
+            nb.np = base + 6;
+        }
+        t = nb.conv(t, c->base, 3, 1, 1, true, false);
+        P.ops.back().res = feat;
+        for (int f = 1; f < c->up; f *= 2) t = nb.deconv(t, c->base);
+        nb.conv(t, c->out_ch, 3, 1, 1, true, false);
     }
     nb.finish(c->dtype);
     return 0;
@@ -1032,11 +1056,12 @@ static int rd_forward(const RdPlan& P, const float* x_nchw, const float* const* 
             Conv cv(dt, o.k, o.k, o.s);
             cv.in(xin, B, ti.H, ti.W, ti.C < 8 ? ti.cs : ti.C).w(wp + o.wf[0], o.bias >= 0 ? params[o.bias] : nullptr).out(out, to.H, to.W, to.C).pad(o.pad, o.pad);
             if (o.relu) { cv.lrelu(); cv.d.slope = 0.f; }
+            if (o.res >= 0) cv.res1(rd_t(w8, P.T[o.res]), to.C, 1.f);          // y = conv(x) + res (edsr.py:97-98)
             SG_TRY(cv.run(st));
         } else if (o.type == 1) {
             const void* res = o.res >= 0 ? (w8 + P.T[o.res].off) : nullptr;
             SG_TRY(srcgan_gn_forward(xin.p, ti.cs, res, o.res >= 0 ? P.T[o.res].cs : 0, out.p, to.cs, params[o.w], params[o.w + 1],
-                                     (float*)(w8 + o.stats), B, (long)ti.H * ti.W, ti.C, 32, 1e-5f, o.relu, dt, gnscr, st));
+                                     (float*)(w8 + o.stats), B, (long)ti.H * ti.W, ti.C, 32, 1e-5f, o.relu, o.slope, dt, gnscr, st));
         } else if (o.type == 2) {
             for (int q = 0; q < 4; ++q)
                 SG_TRY(Conv(dt, 1, 1, 1).in(xin, B, ti.H, ti.W, ti.C).w(wp + o.wf[q]).out(out, ti.H, ti.W, to.C)
@@ -1077,7 +1102,7 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         char key[64]; snprintf(key, sizeof(key), "%s_bwd", tag);
         SG_TRY(packs.run(key, params[0], st));
     }
-    std::vector<char> written(P.T.size(), 0);
+    std::vector<char> written(P.T.size(), 0), seen_param(P.nparams + 2, 0);
     auto gt = [&](int id) { return tref(s8 + P.g[id], P.T[id].cs); };
     {
         const RdT& last = P.T.back();
@@ -1093,8 +1118,16 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         TRef xin = rd_t(w8, ti), dy = gt(o.out);
         const bool need_dx = o.in != 0;
         TRef dx = need_dx ? gt(o.in) : TNULL;
-        const bool acc = need_dx && written[o.in];
+        bool acc = need_dx && written[o.in];
         if (o.type == 0) {
+            if (o.res >= 0) {       // y = conv(x) + res: the residual's gradient is dy itself
+                const RdT tr = P.T[o.res];
+                TRef dr = gt(o.res);
+                if (!written[o.res]) SG_HIP(hipMemcpyAsync(dr.p, dy.p, (size_t)B * tr.H * tr.W * tr.cs * P.esz, hipMemcpyDeviceToDevice, (hipStream_t)st));
+                else SG_TRY(srcgan_add_inplace(dr.p, tr.cs, 0, dy.p, to.cs, 0, nullptr, 0, 0, 0.f, (long)B * tr.H * tr.W, tr.C, dt, st));
+                written[o.res] = 1;
+                acc = need_dx && written[o.in];
+            }
             const bool fused_bias = o.bias >= 0 && o.k == 3 && G(o.w);
             if (G(o.w))
                 SG_TRY(wgrad_call(dt, dy, to.H, to.W, to.C, xin, B, ti.H, ti.W, ti.C, o.k, o.k, o.s, o.pad, o.pad, lay_fwd(ti.C, o.k, o.k), 1.f, slab, G(o.w), st,
@@ -1127,14 +1160,15 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
                 written[o.in] = 1;
             }
         } else if (o.type == 1) {
-            void* dres = nullptr; int dres_cs = 0;
-            if (o.res >= 0) {       // a block input always meets its shortcut first in this reverse walk: plain store
-                SG_REQUIRE(!written[o.res], "%s backward: internal error (residual gradient order)", tag);
-                dres = s8 + P.g[o.res]; dres_cs = P.T[o.res].cs; written[o.res] = 1;
+            void* dres = nullptr; int dres_cs = 0, dres_acc = 0;
+            if (o.res >= 0) {       // first contribution to the shortcut's source: plain store, later ones add
+                dres = s8 + P.g[o.res]; dres_cs = P.T[o.res].cs; dres_acc = written[o.res]; written[o.res] = 1;
             }
             SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (GroupNorm input has two consumers or a fused activation)", tag);
+            const int pacc = seen_param[o.w];       // a GroupNorm module applied more than once (edsr.py:41,47,49): gradients add
+            seen_param[o.w] = 1;
             SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, params[o.w], (const float*)(w8 + o.stats),
-                                      dx.p, ti.cs, dres, dres_cs, G(o.w), G(o.w + 1), 0, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
+                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
             written[o.in] = 1;
         } else if (o.type == 2) {
             if (G(o.w))     // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2
@@ -1173,11 +1207,11 @@ extern "C" size_t srcgan_srnet_bwd_scratch_bytes(const srcgan_srnet_cfg* c) { Rd
 extern "C" int srcgan_srnet_forward(const srcgan_srnet_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* st) {
     RdPlan P;
     SG_TRY(sr_plan(c, P));
-    return rd_forward(P, x_nchw, params, ws, y_nchw, c->kind == 0 ? "espcn" : "srcnn", st);
+    return rd_forward(P, x_nchw, params, ws, y_nchw, c->kind == 0 ? "espcn" : c->kind == 1 ? "srcnn" : "edsr", st);
 }
 extern "C" int srcgan_srnet_backward(const srcgan_srnet_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
                                      float* const* grads, void* st) {
     RdPlan P;
     SG_TRY(sr_plan(c, P));
-    return rd_backward(P, dy_nchw, params, ws, scratch, grads, c->kind == 0 ? "espcn" : "srcnn", st);
+    return rd_backward(P, dy_nchw, params, ws, scratch, grads, c->kind == 0 ? "espcn" : c->kind == 1 ? "srcnn" : "edsr", st);
 }

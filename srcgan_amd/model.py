@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _native as N
 
-__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "ESPCN", "SRCNN", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
+__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "ESPCN", "SRCNN", "EDSR", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
            "get_deconv_params"]
 
 
@@ -394,17 +394,18 @@ class _SrNetFn(torch.autograd.Function):
     def forward(ctx, x, cfg_items, *params):
         N.require_cuda(x, "ESPCN/SRCNN forward")
         lib = N.lib()
-        kind, in_ch, out_ch, up, base, dtype = cfg_items
+        kind, in_ch, out_ch, up, base, dtype = cfg_items[:6]
+        nres = cfg_items[6] if len(cfg_items) > 6 else 0
         if x.dim() != 4 or x.shape[1] != in_ch:
             raise ValueError(f"expected [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
         B, _, H, W = x.shape
-        cfg = N.SrNetCfg(kind, in_ch, out_ch, up, base, B, H, W, dtype)
+        cfg = N.SrNetCfg(kind, in_ch, out_ch, up, base, B, H, W, dtype, nres)
         for p in params:
             N.require_cuda(p, "parameter")
         plist = [p.detach().contiguous() for p in params]
         ws = N.workspace(lib.srcgan_srnet_ws_bytes(C.byref(cfg)), x.device)
-        f = up if kind == 0 else 1
+        f = 1 if kind == 1 else up
         y = torch.empty(B, out_ch, H * f, W * f, dtype=torch.float32, device=x.device)
         N.check(lib.srcgan_srnet_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(), N.stream_ptr(x.device)),
                 "srcgan_srnet_forward")
@@ -475,6 +476,41 @@ class SRCNN(nn.Module):
 
     def forward(self, x):
         return _SrNetFn.apply(x, (*self._cfg, N.dtype_id(self.compute_dtype)), *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
+
+
+class _EdsrBlock(_HolderOnly):
+    """Parameter holder of edsr.py:37-50 ResnetBlock: conv1, conv2, ONE GroupNorm(32) applied after each."""
+
+    def __init__(self, num_channel):
+        super().__init__()
+        self.conv1 = nn.Conv2d(num_channel, num_channel, 3, 1, 1)
+        self.conv2 = nn.Conv2d(num_channel, num_channel, 3, 1, 1)
+        self.gn = nn.GroupNorm(32, num_channel)
+        self.activation = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+
+
+class EDSR(nn.Module):
+    """Drop-in for reference ``model.EDSR`` (src/model/edsr.py:68-110): ``EDSR(in_ch, ou_ch, upscale_factor=2, base_channel=64,
+    num_residuals=50)``."""
+
+    def __init__(self, in_ch, ou_ch, upscale_factor=2, base_channel=64, num_residuals=50, dtype=None):
+        super().__init__()
+        self.input_conv = nn.Conv2d(in_ch, base_channel, kernel_size=3, stride=1, padding=1)
+        self.residual_layers = nn.Sequential(*[_EdsrBlock(base_channel) for _ in range(num_residuals)])
+        self.mid_conv = nn.Conv2d(base_channel, base_channel, kernel_size=3, stride=1, padding=1)
+        self.upscale_layers = nn.Sequential(*[nn.ConvTranspose2d(base_channel, base_channel, 2, 2, 0, bias=False)
+                                              for _ in range(int(math.log2(upscale_factor)))])
+        self.output_conv = nn.Conv2d(base_channel, ou_ch, kernel_size=3, stride=1, padding=1)
+        _kaiming_like_reference(self)
+        self._cfg = (2, in_ch, ou_ch, upscale_factor, base_channel)
+        self._nres = num_residuals
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, x):
+        return _SrNetFn.apply(x, (*self._cfg, N.dtype_id(self.compute_dtype), self._nres), *self.parameters())
 
     def extra_repr(self):
         return f"native gfx950, compute_dtype={self.compute_dtype}"

@@ -213,8 +213,8 @@ def nearest_resize(x: torch.Tensor, scale_factor: float) -> torch.Tensor:
 
 
 def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = 32, *, res: Optional[torch.Tensor] = None,
-               relu: bool = False, eps: float = 1e-5):
-    """GroupNorm (+ residual + ReLU) on NHWC [B,H,W,C].  Returns (y, stats[B,G,2] = {mean, rstd})."""
+               relu: bool = False, eps: float = 1e-5, slope: float = 0.0):
+    """GroupNorm (+ residual + (Leaky)ReLU) on NHWC [B,H,W,C].  Returns (y, stats[B,G,2] = {mean, rstd})."""
     N.require_cuda(x, "group_norm")
     lib = N.lib()
     B, H, W, Cc = x.shape
@@ -222,13 +222,13 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int 
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
     scr = torch.empty(lib.srcgan_gn_scratch_floats(B, Cc), dtype=torch.float32, device=x.device)
     N.check(lib.srcgan_gn_forward(x.data_ptr(), Cc, res.data_ptr() if res is not None else None, Cc, y.data_ptr(), Cc,
-                                  gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), B, H * W, Cc, G, eps, int(relu),
+                                  gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), B, H * W, Cc, G, eps, int(relu), slope,
                                   N.dtype_id(x.dtype), scr.data_ptr(), N.stream_ptr(x.device)), "srcgan_gn_forward")
     return y, stats
 
 
 def group_norm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor, G: int = 32, *,
-                   yact: Optional[torch.Tensor] = None, want_dres: bool = False):
+                   yact: Optional[torch.Tensor] = None, want_dres: bool = False, slope: float = 0.0):
     """Backward of group_norm: returns (dx, dres | None, dgamma, dbeta); yact = forward output when ReLU was applied."""
     N.require_cuda(x, "group_norm_bwd")
     lib = N.lib()
@@ -239,7 +239,7 @@ def group_norm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats
     dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
     scr = torch.empty(lib.srcgan_gn_scratch_floats(B, Cc), dtype=torch.float32, device=x.device)
     N.check(lib.srcgan_gn_backward(dy.data_ptr(), Cc, yact.data_ptr() if yact is not None else None, Cc, x.data_ptr(), Cc,
-                                   gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(), Cc, dres.data_ptr() if want_dres else None, Cc,
-                                   dgamma.data_ptr(), dbeta.data_ptr(), 0, B, H * W, Cc, G, N.dtype_id(x.dtype), scr.data_ptr(),
+                                   gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(), Cc, dres.data_ptr() if want_dres else None, Cc, 0,
+                                   dgamma.data_ptr(), dbeta.data_ptr(), 0, slope, B, H * W, Cc, G, N.dtype_id(x.dtype), scr.data_ptr(),
                                    N.stream_ptr(x.device)), "srcgan_gn_backward")
     return dx, dres, dgamma, dbeta

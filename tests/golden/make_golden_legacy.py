@@ -63,6 +63,22 @@ def small_sr():
         print(tag, tuple(y.shape), float(loss))
 
 
+def edsr_golden():
+    """EDSR (reference src/model/edsr.py:68-110) at reduced depth."""
+    from model import EDSR
+    for tag, args, shape in (("edsr_x2", (1, 1, 2, 64, 3), (2, 1, 16, 20)), ("edsr_x4", (3, 3, 4, 32, 2), (1, 3, 12, 10))):
+        torch.manual_seed(0)
+        m = EDSR(*args)
+        x = torch.rand(*shape)
+        t = torch.rand(shape[0], args[1], shape[2] * args[2], shape[3] * args[2])
+        y = m(x)
+        loss = nn.L1Loss()(y, t)
+        loss.backward()
+        np.savez(os.path.join(OUT, f"{tag}.npz"), cfg=np.array(args), x=npy(x), t=npy(t), y=npy(y), loss=npy(loss), **sd_np(m),
+                 **{"grad/" + k: npy(p.grad) for k, p in m.named_parameters()})
+        print(tag, tuple(y.shape), float(loss))
+
+
 def cas_default():
     """Two CasSRC.optimize_parameters steps in the reference's DEFAULT configuration (trainCas.py:169-171: --SRModel ESPCN,
     --CModel ResDeconv, --up 2): losses and PSNRs only -- the build reproduces both networks' seeded initial weights."""
@@ -106,3 +122,4 @@ if __name__ == "__main__":
     small_sr()
     cas_default()
     metrics_golden()
+    edsr_golden()

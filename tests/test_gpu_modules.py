@@ -296,13 +296,15 @@ def test_resdeconv_bf16_vs_oracle():
         assert cos(p.grad.cpu(), sd[k].grad) > 0.75, (k, cos(p.grad.cpu(), sd[k].grad))
 
 
-@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn"])
+@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn", "edsr_x2", "edsr_x4"])
 def test_small_sr_models_golden_f32(tag):
     """Native ESPCN (the reference's default --SRModel) and SRCNN against reference outputs, losses and every parameter gradient."""
-    from srcgan_amd import ESPCN, SRCNN, L1Loss
+    from srcgan_amd import ESPCN, SRCNN, EDSR, L1Loss
     g = load_golden(tag)
-    ic, oc, up = [int(v) for v in g["cfg"]]
-    net = _load((SRCNN if tag == "srcnn" else ESPCN)(ic, oc, up, dtype="fp32"), sub(g, "sd/"))
+    cfg = [int(v) for v in g["cfg"]]
+    ic, oc, up = cfg[:3]
+    net = EDSR(*cfg, dtype="fp32") if tag.startswith("edsr") else (SRCNN if tag == "srcnn" else ESPCN)(ic, oc, up, dtype="fp32")
+    net = _load(net, sub(g, "sd/"))
     y = net(torch.from_numpy(g["x"]).cuda())
     assert rel_err(y.cpu(), g["y"]) < F32_TOL
     loss = L1Loss()(y, torch.from_numpy(g["t"]).cuda())
@@ -310,7 +312,11 @@ def test_small_sr_models_golden_f32(tag):
     loss.backward()
     grads = sub(g, "grad/")
     for k, p in net.named_parameters():
-        assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+        if float(grads[k].abs().max()) < 1e-7:
+            # mathematically zero (a conv bias in front of a one-channel-per-group GroupNorm, edsr_x4): rounding residue in both
+            assert float(p.grad.abs().max()) < 1e-6, k
+        else:
+            assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
 
 
 def test_espcn_bf16_vs_oracle():

@@ -226,17 +226,18 @@ def test_resdeconv(tag):
         assert rel_err(sd[k].grad, v) < 1e-4, k
 
 
-@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn"])
+@pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn", "edsr_x2", "edsr_x4"])
 def test_small_sr_models(tag):
     """ESPCN (espcn.py; the CLI default --SRModel) and SRCNN (srcnn.py) restatements against reference outputs / gradients,
     and the seeded holders of the package against the reference's initial weights."""
     import srcgan_amd
     g = load_golden(tag)
-    ic, oc, up = [int(v) for v in g["cfg"]]
+    cfg = [int(v) for v in g["cfg"]]
+    ic, oc, up = cfg[:3]
     ref = sub(g, "sd/")
     sd = _req(ref)
     x = torch.from_numpy(g["x"])
-    y = oracle.srcnn_forward(sd, x) if tag == "srcnn" else oracle.espcn_forward(sd, x, up)
+    y = oracle.srcnn_forward(sd, x) if tag == "srcnn" else oracle.edsr_forward(sd, x) if tag.startswith("edsr") else oracle.espcn_forward(sd, x, up)
     loss = oracle.l1_loss(y, torch.from_numpy(g["t"]))
     loss.backward()
     assert rel_err(y, g["y"]) < TOL
@@ -244,7 +245,7 @@ def test_small_sr_models(tag):
     for k, v in sub(g, "grad/").items():
         assert rel_err(sd[k].grad, v) < TOL, k
     torch.manual_seed(0)
-    net = (srcgan_amd.SRCNN if tag == "srcnn" else srcgan_amd.ESPCN)(ic, oc, up)
+    net = srcgan_amd.EDSR(*cfg) if tag.startswith("edsr") else (srcgan_amd.SRCNN if tag == "srcnn" else srcgan_amd.ESPCN)(ic, oc, up)
     assert list(net.state_dict().keys()) == list(ref.keys())
     for k, v in ref.items():
         assert torch.equal(net.state_dict()[k], v), k
