@@ -241,6 +241,8 @@ typedef struct srcgan_rddbnet_cfg {
                           upconv1/upconv2, HRconv applied 8 times, conv_last with bias; `up` = 2 ('x2': upconv1 twice) or
                           4 ('x4').  2: model/model.py:347-391 legacy RDDBNet (its trunk result is discarded by the
                           reference's forward: not computed, no gradients); `up` = 1, 2 or 4.
+                          3: srdn.py:56-74 SRDN (conv_first, RRDB_encoder, + skip, RRDB_decoder, + skip, conv_last; its trunk_conv
+                          is never applied: pass it, it gets no gradient); `up` = 1, `nb` = RRDBs per stack.
                           params/grads follow the respective state_dict order. */
 } srcgan_rddbnet_cfg;
 int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);

@@ -32,7 +32,7 @@ __all__ = [
     "bilinear_down", "nearest_down", "cas_forward_sr_inputs", "ImagePoolOracle",
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
-    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "edsr_forward", "metric_ae", "metric_ssim",
+    "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "edsr_forward", "srdn_forward", "metric_ae", "metric_ssim",
 ]
 
 
@@ -228,6 +228,18 @@ def edsr_forward(sd: State, x: Tensor) -> Tensor:
         t = F.conv_transpose2d(t, sd[f"upscale_layers.{j}.weight"], None, 2, 0)
         j += 1
     return c("output_conv", t)
+
+
+def srdn_forward(sd: State, x: Tensor) -> Tensor:
+    """SRDN.forward, srdn.py:67-74 (trunk_conv is defined and never applied)."""
+    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    for stack in ("RRDB_encoder", "RRDB_decoder"):
+        t, i = fea, 0
+        while f"{stack}.{i}.RDB1.conv1.weight" in sd:
+            t = rrdb_forward(sd, f"{stack}.{i}.", t)
+            i += 1
+        fea = fea + t
+    return F.conv2d(fea, sd["conv_last.weight"], None, 1, 1)
 
 
 def rddbnet_keys(nb: int, up: int) -> List[str]:

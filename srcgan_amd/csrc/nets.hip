@@ -133,6 +133,8 @@ struct RddbPlan {
     int p_first_w, p_first_b, p_rdb0, p_trunk_w, p_trunk_b, p_up0, p_dn0, p_last_w;
     // legacy generators (model/model.py:347-440): tail = nearest x2 / shared 3x3 convs + LeakyReLU, conv_last with bias
     int legacy, ntail, nlw, p_lg[3], p_last_b;
+    int nrr;                  // RRDBs in the trunk (legacy 3 = SRDN: encoder + decoder = 2 nb, srdn.py:56-74)
+    int prdb(int r) const { return p_rdb0 + r * 10 + ((legacy == 3 && r >= 3 * nb) ? 2 : 0); }     // SRDN: trunk_conv's two parameters sit between the stacks
     struct TailOp { int conv, w, hin, win, hout, wout; size_t out; } tail[16];     // conv: 1 = 3x3 conv w + LReLU, 0 = nearest x2
     size_t lw_f[3], lw_d[3];
 };
@@ -148,10 +150,12 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     SG_REQUIRE(c->up >= 1 && (c->up & (c->up - 1)) == 0 && c->up <= 16, "rddbnet: upscale_factor must be a power of two <= 16");
     SG_REQUIRE(c->down >= 0 && (c->down == 0 || ((c->down & (c->down - 1)) == 0 && c->down <= 16)), "rddbnet: bad down factor");
     SG_REQUIRE(!(c->down > 1 && c->up > 1), "rddbnet: up and down are exclusive");
-    SG_REQUIRE(c->legacy >= 0 && c->legacy <= 2, "rddbnet: legacy must be 0, 1 or 2");
-    SG_REQUIRE(c->legacy == 0 || (c->down == 0 && (c->up == 2 || c->up == 4 || (c->legacy == 2 && c->up == 1))),
+    SG_REQUIRE(c->legacy >= 0 && c->legacy <= 3, "rddbnet: legacy must be 0..3");
+    SG_REQUIRE(c->legacy == 0 || c->legacy == 3 || (c->down == 0 && (c->up == 2 || c->up == 4 || (c->legacy == 2 && c->up == 1))),
                "rddbnet: legacy generators take mode x2 / x4 (legacy RDDBNet also x1) and no down factor");
-    P.legacy = c->legacy; P.ntail = 0; P.nlw = 0;
+    SG_REQUIRE(c->legacy != 3 || (c->up == 1 && c->down == 0), "rddbnet: SRDN keeps the resolution (its upscale_factor is unused, srdn.py:67-74): pass up = 1");
+    P.legacy = c->legacy == 3 ? 3 : c->legacy; P.ntail = 0; P.nlw = 0;
+    P.nrr = c->legacy == 3 ? 2 * c->nb : (c->legacy == 2 ? 0 : c->nb);
     P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
     P.nf = c->nf; P.gc = c->gc; P.nb = c->nb; P.C = c->nf + 4 * c->gc;
     P.B = c->B; P.H = c->H; P.W = c->W;
@@ -170,10 +174,11 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     // and of the dense wgrad is then >= 1 KiB contiguous (64-byte pieces at a 384-byte pixel stride ran at half rate)
     P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
     P.szA = align_up((size_t)P.nplane * P.plane_bytes, 256);
-    P.A = b.take(P.szA * (c->legacy == 2 ? 1 : 3 * c->nb));        // legacy RDDBNet discards its trunk: one buffer holds conv_first's output
+    P.A = b.take(P.szA * (c->legacy == 2 ? 1 : 3 * P.nrr));        // legacy RDDBNet discards its trunk: one buffer holds conv_first's output
     P.T = b.take(B * P.Ht * P.Wt * c->nf * e);
-    for (int s = 0; s <= (c->legacy ? 0 : P.nst); ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
-    if (c->legacy) {
+    for (int s = 0; s <= ((c->legacy == 1 || c->legacy == 2) ? 0 : P.nst); ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    if (c->legacy == 3) P.U[0] = P.T;                  // SRDN: conv_last reads trunk output + skip, accumulated in place in T
+    if (c->legacy == 1 || c->legacy == 2) {
         int h = P.Ht, w = P.Wt;
         auto op = [&](int conv, int wi) {
             RddbPlan::TailOp& o = P.tail[P.ntail++];
@@ -199,8 +204,9 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     auto pk = [&](int rows, int k, int taps) { return wb.take(srcgan_packed_weight_bytes(rows, k, taps, c->dtype)); };
     P.w_first_f = pk(c->nf, P.in_cs, 9); P.w_first_d = pk(c->in_ch, c->nf, 9);
     for (int s = 0; s < P.ndn; ++s) { P.w_dn_f[s] = pk(c->nf, c->nf, 9); for (int q = 0; q < 4; ++q) P.w_dn_d[s][q] = pk(c->nf, c->nf, 4); }
-    P.w_rdb_f.resize(c->nb * 15); P.w_rdb_d.resize(c->nb * 15);
-    for (int i = 0; i < c->nb * 3; ++i)
+    const int nrdb = (P.nrr ? P.nrr : c->nb) * 3;
+    P.w_rdb_f.resize(nrdb * 5); P.w_rdb_d.resize(nrdb * 5);
+    for (int i = 0; i < nrdb; ++i)
         for (int k = 0; k < 5; ++k) {
             const int cin = c->nf + k * c->gc, cout = k < 4 ? c->gc : c->nf;
             P.w_rdb_f[i * 5 + k] = pk(cout, cin, 9);
@@ -212,7 +218,7 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     // dense-block backward: slice j of the block input gets its gradient from ONE conv over the concatenated
     // output-gradients [dy5 | dy4 | ... | dy_{j+1}] (rows = slice channels, K = nf + (4-j)*gc)
     P.w_rdb_d0 = wb.off;
-    for (int i = 0; i < c->nb * 3; ++i)
+    for (int i = 0; i < nrdb; ++i)
         for (int j = 0; j < 5; ++j) P.w_rdb_d[i * 5 + j] = pk(j == 0 ? c->nf : c->gc, c->nf + (4 - j) * c->gc, 9);
     P.w_rdb_dsz = wb.off - P.w_rdb_d0;
     P.total = align_up(P.wpk + wb.off + 256, 256);
@@ -222,10 +228,11 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     P.p_dn0 = n; n += 2 * P.ndn;
     P.p_rdb0 = n; n += c->nb * 30;
     P.p_trunk_w = n++; P.p_trunk_b = n++;
-    if (c->legacy) { P.p_up0 = n; for (int k = 0; k < P.nlw; ++k) { P.p_lg[k] = n; n += 2; } }
+    if (c->legacy == 3) n += c->nb * 30;          // RRDB_decoder
+    if (c->legacy == 1 || c->legacy == 2) { P.p_up0 = n; for (int k = 0; k < P.nlw; ++k) { P.p_lg[k] = n; n += 2; } }
     else { P.p_up0 = n; n += P.nst; }
     P.p_last_w = n++;
-    P.p_last_b = c->legacy ? n++ : -1;
+    P.p_last_b = (c->legacy == 1 || c->legacy == 2) ? n++ : -1;
     P.nparams = n;
     return 0;
 }
@@ -243,8 +250,8 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     const size_t e = P.esz, B = c->B;
     Bump b;
     Q.dout = b.take(B * P.HO * P.WO * P.out_cs * e);
-    for (int s = 0; s <= (P.legacy ? 0 : P.nst); ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
-    if (P.legacy) { Q.dU[1] = b.take(B * P.HO * P.WO * c->nf * e); Q.dU[2] = b.take(B * P.HO * P.WO * c->nf * e); }   // ping-pong
+    for (int s = 0; s <= ((P.legacy == 1 || P.legacy == 2) ? 0 : P.nst); ++s) Q.dU[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
+    if (P.legacy == 1 || P.legacy == 2) { Q.dU[1] = b.take(B * P.HO * P.WO * c->nf * e); Q.dU[2] = b.take(B * P.HO * P.WO * c->nf * e); }   // ping-pong
     Q.dT = b.take(B * P.Ht * P.Wt * c->nf * e);
     Q.szP = align_up((size_t)P.nplane * P.plane_bytes, 256);
     for (int i = 0; i < 3; ++i) Q.Pg[i] = b.take(Q.szP);
@@ -255,7 +262,7 @@ static void rddb_bwd_plan(const srcgan_rddbnet_cfg* c, const RddbPlan& P, RddbBw
     mx(wgrad_slab(c->B, c->H, c->W, c->nf, P.in_cs, 3, 3, 1));
     for (int k = 0; k < 5; ++k) mx(wgrad_slab(c->B, P.Ht, P.Wt, k < 4 ? c->gc : c->nf, c->nf + k * c->gc, 3, 3, 1));
     mx(wgrad_slab(c->B, P.Ht, P.Wt, c->nf, c->nf, 3, 3, 1));
-    for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
+    for (int s = 0; s < ((P.legacy == 1 || P.legacy == 2) ? 0 : P.nst); ++s) mx(wgrad_slab(c->B, P.Ht << s, P.Wt << s, c->nf, c->nf, 2, 2, 2));
     for (int k = 0; k < P.ntail; ++k) if (P.tail[k].conv) mx(wgrad_slab(c->B, P.tail[k].hout, P.tail[k].wout, c->nf, c->nf, 3, 3, 1));
     for (int s = 0; s < P.ndn; ++s) mx(wgrad_slab(c->B, c->H >> (s + 1), c->W >> (s + 1), c->nf, c->nf, 3, 3, 2));
     mx(wgrad_slab(c->B, P.HO, P.WO, c->out_ch, c->nf, 3, 3, 1));
@@ -289,20 +296,20 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
     packs.add(params[P.p_first_w], wp + P.w_first_f, nf, c->in_ch, 3, 3, (long)c->in_ch * 9, 9, 3, 1, 0);
     for (int s = 0; s < P.ndn; ++s)
         packs.add(params[P.p_dn0 + 2 * s], wp + P.w_dn_f[s], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
-    for (int i = 0; i < c->nb * 3; ++i)
+    for (int i = 0; i < P.nrr * 3; ++i)
         for (int k = 0; k < 5; ++k) {
             const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
-            packs.add(params[P.p_rdb0 + (i * 5 + k) * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0);
+            packs.add(params[P.prdb(i) + k * 2], wp + P.w_rdb_f[i * 5 + k], cout, cin, 3, 3, (long)cin * 9, 9, 3, 1, 0);
         }
-    packs.add(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
-    for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s)
+    if (P.legacy != 3) packs.add(params[P.p_trunk_w], wp + P.w_trunk_f, nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
+    for (int s = 0; s < ((P.legacy == 1 || P.legacy == 2) ? 0 : P.nst); ++s)
         for (int q = 0; q < 4; ++q)   // ConvTranspose2d weight [ci][co][2][2]; parity (a,b) = q: rows = co, k = ci
             packs.add(params[P.p_up0 + s], wp + P.w_up_f[s][q], nf, nf, 1, 1, 4, (long)nf * 4, 0, 0, q);
     for (int k = 0; k < P.nlw; ++k)
         packs.add(params[P.p_lg[k]], wp + P.lw_f[k], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     packs.add(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
 
-    SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : "rddb_fwd", params[0], st));
+    SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : P.legacy == 3 ? "srdn_fwd" : "rddb_fwd", params[0], st));
 
     // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -321,30 +328,39 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
         fea = o;
     }
     // RRDB trunk (rddb.py:62-68,78-82).  The legacy RDDBNet computes it and throws it away (model.py:382-383): skipped.
-    for (int i = 0; i < (P.legacy == 2 ? 0 : c->nb); ++i) {
+    for (int i = 0; i < P.nrr; ++i) {
         for (int j = 0; j < 3; ++j) {
             const int r = i * 3 + j;
             TRef A = Abuf(r);
             for (int k = 0; k < 4; ++k) {
                 const int cin = nf + k * gc;
-                SG_TRY(Conv(dt, 3, 3, 1).in(A, B, H, W, cin).w(wp + P.w_rdb_f[r * 5 + k], params[P.p_rdb0 + (r * 5 + k) * 2 + 1])
+                SG_TRY(Conv(dt, 3, 3, 1).in(A, B, H, W, cin).w(wp + P.w_rdb_f[r * 5 + k], params[P.prdb(r) + k * 2 + 1])
                            .out(sl(A, cin), H, W, gc).pad(1, 1).lrelu().run(st));
             }
             // conv5 + residual(s) -> channels [0,nf) of the next dense buffer (or the trunk output)
-            const bool last = (r == c->nb * 3 - 1);
+            const bool last = (r == P.nrr * 3 - 1);
             TRef dst = last ? T_(P.T, nf) : Abuf(r + 1);
             Conv cv(dt, 3, 3, 1);
-            cv.in(A, B, H, W, P.C).w(wp + P.w_rdb_f[r * 5 + 4], params[P.p_rdb0 + (r * 5 + 4) * 2 + 1]).out(dst, H, W, nf).pad(1, 1);
+            cv.in(A, B, H, W, P.C).w(wp + P.w_rdb_f[r * 5 + 4], params[P.prdb(r) + 4 * 2 + 1]).out(dst, H, W, nf).pad(1, 1);
             if (j < 2) cv.alpha(0.2f).res1(A, nf, 1.f);
             else cv.alpha(0.04f).res1(A, nf, 0.2f).res2(Abuf(i * 3), nf, 1.f);   // RRDB: 0.2*(0.2*x5 + x_rdb3) + x_rrdb
             SG_TRY(cv.run(st));
         }
+        if (P.legacy == 3 && i == c->nb - 1) {       // SRDN: fea = fea + RRDB_encoder(fea) (srdn.py:70-71), in the decoder's first buffer
+            TRef d0 = Abuf((i + 1) * 3);
+            SG_TRY(srcgan_add_inplace_planes(d0.p, d0.cs, 0, d0.plane, trunk_in.p, trunk_in.cs, 0, trunk_in.plane, nullptr, 0, 0, 0, 0.f,
+                                             (long)B * H * W, nf, dt, st));
+        }
+    }
+    if (P.legacy == 3) {       // fea = fea + RRDB_decoder(fea) (srdn.py:72-73): T += fea1, then conv_last reads T (= U[0])
+        TRef f1 = Abuf(c->nb * 3), Tt = T_(P.T, nf);
+        SG_TRY(srcgan_add_inplace_planes(Tt.p, Tt.cs, 0, 0, f1.p, f1.cs, 0, f1.plane, nullptr, 0, 0, 0, 0.f, (long)B * H * W, nf, dt, st));
     }
     // trunk_conv + global skip (rddb.py:109-110)
-    if (P.legacy != 2)
+    if (P.legacy != 2 && P.legacy != 3)
         SG_TRY(Conv(dt, 3, 3, 1).in(T_(P.T, nf), B, H, W, nf).w(wp + P.w_trunk_f, params[P.p_trunk_b]).out(T_(P.U[0], nf), H, W, nf)
                    .pad(1, 1).res1(trunk_in, nf, 1.f).run(st));
-    if (P.legacy) {
+    if (P.legacy == 1 || P.legacy == 2) {
         // legacy tail (model.py:384-390, 427-439): [nearest x2 -> 3x3 conv -> LeakyReLU] stages, HRconv applied repeatedly
         TRef cur = P.legacy == 2 ? trunk_in : T_(P.U[0], nf);
         for (int k = 0; k < P.ntail; ++k) {
@@ -400,20 +416,20 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         PackList packs(dt, wp);
         const WLayout L = lay_dgrad_s1(nf, 3, 3);
         packs.add(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
-        for (int s = 0; s < (P.legacy ? 0 : P.nst); ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
+        for (int s = 0; s < ((P.legacy == 1 || P.legacy == 2) ? 0 : P.nst); ++s)   // deconv dgrad = 2x2 s2 conv over dy: rows = ci, k = co, tap = (a,b)
             packs.add(params[P.p_up0 + s], wp + P.w_up_d[s], nf, nf, 2, 2, (long)nf * 4, 4, 2, 1, 0);
         for (int k = 0; k < P.nlw; ++k)
             packs.add(params[P.p_lg[k]], wp + P.lw_d[k], nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
-        packs.add(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
+        if (P.legacy != 3) packs.add(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         SG_HIP(hipMemsetAsync(wp + P.w_rdb_d0, 0, P.w_rdb_dsz, (hipStream_t)st));
-        for (int r = 0; r < (P.legacy == 2 ? 0 : c->nb * 3); ++r) {
+        for (int r = 0; r < P.nrr * 3; ++r) {
             const float a5 = (r % 3 == 2) ? 0.04f : 0.2f;       // d(x5)/d(block out), RDB3 carries the RRDB 0.2 too
             for (int j = 0; j < 5; ++j) {
                 const int rows = j == 0 ? nf : gc, ss = j == 0 ? 0 : nf + (j - 1) * gc, ktot = nf + (4 - j) * gc;
                 for (int m = 5; m > j; --m) {                   // block of K coming from forward conv m
                     const int cin_m = nf + (m - 1) * gc, cout_m = m == 5 ? nf : gc;
                     const int k_off = m == 5 ? 0 : nf + (4 - m) * gc;
-                    packs.add(params[P.p_rdb0 + (r * 5 + m - 1) * 2], wp + P.w_rdb_d[r * 5 + j], rows, cout_m, 3, 3,
+                    packs.add(params[P.prdb(r) + (m - 1) * 2], wp + P.w_rdb_d[r * 5 + j], rows, cout_m, 3, 3,
                                                    9, (long)cin_m * 9, -3, -1, (long)ss * 9 + 8, k_off, ktot, m == 5 ? a5 : 1.f);
                 }
             }
@@ -431,6 +447,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             packs.add(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off);
         }
         SG_TRY(packs.run(P.legacy == 1 ? (dx_nchw ? "rddbB_bwd_dx" : "rddbB_bwd") : P.legacy == 2 ? (dx_nchw ? "rddbL_bwd_dx" : "rddbL_bwd")
+                                       : P.legacy == 3 ? (dx_nchw ? "srdn_bwd_dx" : "srdn_bwd")
                                        : (dx_nchw ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st));
     }
 
@@ -438,7 +455,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     TRef dout = S_(Q.dout, P.out_cs);
     SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dout.p, B, c->out_ch, P.HO, P.WO, P.out_cs, dt, st));
     TRef dU0 = S_(Q.dU[0], nf);
-    if (P.legacy) {
+    if (P.legacy == 1 || P.legacy == 2) {
         // ---- legacy tail backward.  dcur = gradient w.r.t. an op's output, already times LeakyReLU' of that output.
         TRef tin = P.legacy == 2 ? Abuf(0) : T_(P.U[0], nf);          // tail input (not an activation output)
         auto obuf = [&](int k) { return k < 0 ? tin : T_(P.tail[k].out, nf); };
@@ -510,23 +527,38 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     if (P.legacy != 2) {
     // U0 = fea + trunk_conv(T): d(trunk_conv out) = dU0, d(fea) += dU0 (joined at the end)
     TRef Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
+    if (P.legacy != 3) {
     if (G(P.p_trunk_w))
         SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st, G(P.p_trunk_b)));
     else if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
+    }
     // Dense gradient buffers (3, rotating): Gd = [dy5 (nf) | dy4 | dy3 | dy2 | dy1] -- the mirror image of the forward
     // dense buffer.  Slice j of the block input gets its gradient from ONE conv over the channel prefix holding
     // dy5..dy_{j+1} (composite transposed weights), so every gradient element is written exactly once: no
     // read-modify-write accumulation, and the same prefix-read / slice-write pattern as forward.
     auto Pg = [&](int g) { return tref(s8 + Q.Pg[g], P.kce, 0, P.plane_bytes); };
+    if (P.legacy == 3) {
+        // SRDN: d(decoder output) = d(fea2) = dU0 itself (no trunk_conv): into the first gradient buffer's channels [0,nf)
+        TRef g0 = Pg(0);
+        SG_HIP(hipMemsetAsync(g0.p, 0, (size_t)cdiv(nf, P.kce) * P.plane_bytes, (hipStream_t)st));
+        SG_TRY(srcgan_add_inplace_planes(g0.p, g0.cs, 0, g0.plane, dU0.p, dU0.cs, 0, 0, nullptr, 0, 0, 0, 0.f, npix_t, nf, dt, st));
+    } else
     SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(Pg(0), H, W, nf).pad(1, 1).run(st));
     (void)dT;
-    for (int i = c->nb - 1; i >= 0; --i) {
+    for (int i = P.nrr - 1; i >= 0; --i) {
+        if (P.legacy == 3 && i == c->nb - 1) {
+            // between the stacks: d(fea1) = d(fea2) + d(decoder input); it feeds the encoder's output AND the skip around it
+            TRef g0 = Pg(0);
+            SG_TRY(srcgan_add_inplace_planes(g0.p, g0.cs, 0, g0.plane, dU0.p, dU0.cs, 0, 0, nullptr, 0, 0, 0, 0.f, npix_t, nf, dt, st));
+            SG_HIP(hipMemsetAsync(dU0.p, 0, (size_t)npix_t * nf * P.esz, (hipStream_t)st));
+            SG_TRY(srcgan_add_inplace_planes(dU0.p, dU0.cs, 0, 0, g0.p, g0.cs, 0, g0.plane, nullptr, 0, 0, 0, 0.f, npix_t, nf, dt, st));
+        }
         for (int j3 = 2; j3 >= 0; --j3) {                  // RDB3, RDB2, RDB1 use Pg(0), Pg(1), Pg(2)
             const int r = i * 3 + j3, g = 2 - j3;
             TRef A = Abuf(r), Gd = Pg(g), nxt = Pg((g + 1) % 3);
             const float a5 = (j3 == 2) ? 0.04f : 0.2f;     // folded into the packed conv5 block; wgrad/bias use it as alpha
             const float bres = (j3 == 2) ? 0.2f : 1.f;     // block-input residual: d(in) += bres * d(out)
-            const int pbase = P.p_rdb0 + r * 10;
+            const int pbase = P.prdb(r);
             for (int m = 5; m >= 1; --m) {
                 // gradient of input slice j = m-1 from [dy5 .. dy_m]
                 const int j = m - 1, ktot = nf + (4 - j) * gc;

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _native as N
 
-__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "ESPCN", "SRCNN", "EDSR", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
+__all__ = ["RDDBNet", "RDDBNetA", "RDDBNetB", "LegacyRDDBNet", "ResDeconv", "ESPCN", "SRCNN", "EDSR", "SRDN", "NLayerDiscriminator", "ResidualDenseBlock_5", "RRDB", "deconv",
            "get_deconv_params"]
 
 
@@ -511,6 +511,32 @@ class EDSR(nn.Module):
 
     def forward(self, x):
         return _SrNetFn.apply(x, (*self._cfg, N.dtype_id(self.compute_dtype), self._nres), *self.parameters())
+
+    def extra_repr(self):
+        return f"native gfx950, compute_dtype={self.compute_dtype}"
+
+
+class SRDN(nn.Module):
+    """Drop-in for reference ``model.SRDN`` (src/model/srdn.py:56-74): conv_first -> RRDB_encoder (nb RRDBs) -> + skip ->
+    RRDB_decoder (nb RRDBs) -> + skip -> conv_last; same resolution in and out (``upscale_factor`` is stored and unused, and
+    ``trunk_conv`` exists in the state_dict but is never applied -- it receives no gradient, as in the reference)."""
+
+    def __init__(self, in_ch, ou_ch, upscale_factor, nf=64, nb=3, gc=32, dtype=None):
+        super().__init__()
+        self.upscale_factor = upscale_factor
+        self.conv_first = nn.Conv2d(in_ch, nf, 3, 1, 1, bias=True)
+        self.RRDB_encoder = nn.Sequential(*[RRDB(nf=nf, gc=gc) for _ in range(nb)])
+        self.trunk_conv = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.RRDB_decoder = nn.Sequential(*[RRDB(nf=nf, gc=gc) for _ in range(nb)])
+        self.conv_last = nn.Conv2d(nf, ou_ch, 3, 1, 1, bias=False)
+        _kaiming_like_reference(self)
+        self._cfg = (in_ch, ou_ch, 1, nf, nb, gc)
+        self.compute_dtype = N.dtype_name(dtype)
+
+    def forward(self, x):
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), 0, 3)
+        skip = {id(self.trunk_conv.weight), id(self.trunk_conv.bias)}
+        return _RddbFn.apply(x, cfg, *[p.detach() if id(p) in skip else p for p in self.parameters()])
 
     def extra_repr(self):
         return f"native gfx950, compute_dtype={self.compute_dtype}"

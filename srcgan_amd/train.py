@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from .losses import GANLoss, L1Loss, PSNRLoss
-from .model import EDSR, ESPCN, SRCNN, NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
+from .model import EDSR, ESPCN, SRCNN, SRDN, NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
 from .optim import Adam
 
 __all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasParams", "set_requires_grad"]
@@ -231,7 +231,7 @@ class CasParams:
 
 
 # name -> constructor(in_ch, out_ch, up) ; the reference resolves these with eval() (trainCas.py:30-31)
-MODEL_REGISTRY = {"RDDBNet": RDDBNet, "ESPCN": ESPCN, "SRCNN": SRCNN, "EDSR": EDSR, "ResDeconv": ResDeconv}
+MODEL_REGISTRY = {"RDDBNet": RDDBNet, "ESPCN": ESPCN, "SRCNN": SRCNN, "EDSR": EDSR, "SRDN": SRDN, "ResDeconv": ResDeconv}
 
 
 class CasSRC:

@@ -79,6 +79,23 @@ def edsr_golden():
         print(tag, tuple(y.shape), float(loss))
 
 
+def srdn_golden():
+    """SRDN (reference src/model/srdn.py:56-74) at tiny width."""
+    from model import SRDN
+    for tag, args, shape in (("srdn_nb1", (3, 3, 2, 16, 1, 8), (2, 3, 14, 18)), ("srdn_nb2", (1, 1, 2, 16, 2, 8), (1, 1, 10, 12))):
+        torch.manual_seed(0)
+        m = SRDN(*args)
+        x = torch.rand(*shape, requires_grad=True)
+        t = torch.rand(shape[0], args[1], shape[2], shape[3])
+        y = m(x)
+        loss = nn.L1Loss()(y, t)
+        loss.backward()
+        np.savez(os.path.join(OUT, f"{tag}.npz"), cfg=np.array(args), x=npy(x), t=npy(t), y=npy(y), loss=npy(loss), dx=npy(x.grad),
+                 nograd=np.array([k for k, p in m.named_parameters() if p.grad is None]), **sd_np(m),
+                 **{"grad/" + k: npy(p.grad) for k, p in m.named_parameters() if p.grad is not None})
+        print(tag, tuple(y.shape), float(loss))
+
+
 def cas_default():
     """Two CasSRC.optimize_parameters steps in the reference's DEFAULT configuration (trainCas.py:169-171: --SRModel ESPCN,
     --CModel ResDeconv, --up 2): losses and PSNRs only -- the build reproduces both networks' seeded initial weights."""
@@ -123,3 +140,4 @@ if __name__ == "__main__":
     cas_default()
     metrics_golden()
     edsr_golden()
+    srdn_golden()

@@ -262,3 +262,25 @@ def test_metrics(tag):
     s, cs = oracle.metric_ssim(p, t, full=True)
     assert abs(float(s) - float(g[f"{tag}/ssim"])) < 1e-6 and abs(float(cs) - float(g[f"{tag}/cs"])) < 1e-6
     assert rel_err(oracle.metric_ssim(p, t, size_average=False), g[f"{tag}/ssim_per_image"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["srdn_nb1", "srdn_nb2"])
+def test_srdn(tag):
+    """SRDN (srdn.py:56-74) restatement against the reference; seeded holder initialisation; trunk_conv gets no gradient."""
+    import srcgan_amd
+    g = load_golden(tag)
+    cfg = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    sd = _req(ref)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.srdn_forward(sd, x)
+    oracle.l1_loss(y, torch.from_numpy(g["t"])).backward()
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < TOL, k
+    assert {str(k) for k in g["nograd"]} == {"trunk_conv.weight", "trunk_conv.bias"}
+    torch.manual_seed(0)
+    net = srcgan_amd.SRDN(*cfg)
+    assert list(net.state_dict().keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert torch.equal(net.state_dict()[k], v), k
