@@ -223,6 +223,8 @@ int srcgan_psnr_from_mse(const float* mse, float* out, void* stream);
 int srcgan_rgb_to_gray(const float* rgb, float* gray, int B, int H, int W, void* stream);
 int srcgan_bilinear_down(const float* src, float* dst, int B, int C, int H, int W, int up, void* stream);
 int srcgan_nearest_resize(const float* src, float* dst, int B, int C, int H, int W, int OH, int OW, void* stream);
+/* bilinear x up (integer, align_corners=False): the second half of the blur of trainCasConst.py:89-92 */
+int srcgan_bilinear_up(const float* src, float* dst, int B, int C, int H, int W, int up, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Whole-network passes (C++ sequencing of the kernels above; one call per

@@ -135,6 +135,7 @@ SIGNATURES = {
     "srcgan_rgb_to_gray": (_I, [_P, _P, _I, _I, _I, _P]),
     "srcgan_bilinear_down": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "srcgan_nearest_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "srcgan_bilinear_up": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "srcgan_resdeconv_num_params": (_I, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_ws_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_bwd_scratch_bytes": (_S, [C.POINTER(ResDeconvCfg)]),

@@ -737,6 +737,32 @@ extern "C" int srcgan_sum2x2_nhwc(const void* src, int s_cs, void* dst, int d_cs
     return 0;
 }
 
+// bilinear x up (integer), align_corners=False, as F.interpolate(scale_factor=up, mode="bilinear") in trainCasConst.py:91-92:
+// src coordinate = (dst + 0.5) / up - 0.5 clamped at 0, neighbour index clamped at the border
+__global__ __launch_bounds__(256) void bilinear_up_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int up, long total) {
+    const int OH = H * up, OW = W * up;
+    const float inv = 1.f / (float)up;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % OW); const long q = e / OW;
+        const int oy = (int)(q % OH); const long bc = q / OH;
+        float sy = ((float)oy + 0.5f) * inv - 0.5f, sx = ((float)ox + 0.5f) * inv - 0.5f;
+        sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float* s = src + (size_t)bc * H * W;
+        dst[e] = (1.f - ly) * ((1.f - lx) * s[(size_t)y0 * W + x0] + lx * s[(size_t)y0 * W + x1]) +
+                 ly * ((1.f - lx) * s[(size_t)y1 * W + x0] + lx * s[(size_t)y1 * W + x1]);
+    }
+}
+extern "C" int srcgan_bilinear_up(const float* src, float* dst, int B, int C, int H, int W, int up, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && up >= 1, "srcgan_bilinear_up: bad arguments");
+    const long total = (long)B * C * H * up * W * up;
+    hipLaunchKernelGGL(bilinear_up_k, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, up, total);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 // nearest resize, torch 'nearest' rule: src = floor(dst * in/out)
 __global__ __launch_bounds__(256) void nearest_resize_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
                                                         int OH, int OW, long total) {

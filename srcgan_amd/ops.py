@@ -201,6 +201,16 @@ def bilinear_down(x: torch.Tensor, up: int) -> torch.Tensor:
     return out
 
 
+def bilinear_up(x: torch.Tensor, up: int) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=up, mode='bilinear') (align_corners=False) for an integer factor (trainCasConst.py:91-92)."""
+    N.require_cuda(x, "bilinear_up")
+    x = x.contiguous().float()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, Cc, H * up, W * up, dtype=torch.float32, device=x.device)
+    N.check(N.lib().srcgan_bilinear_up(x.data_ptr(), out.data_ptr(), B, Cc, H, W, int(up), N.stream_ptr(x.device)), "srcgan_bilinear_up")
+    return out
+
+
 def nearest_resize(x: torch.Tensor, scale_factor: float) -> torch.Tensor:
     """F.interpolate(x, scale_factor=s) with the default 'nearest' mode (train.py:243,248,382)."""
     N.require_cuda(x, "nearest_resize")

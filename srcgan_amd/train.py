@@ -25,7 +25,8 @@ from .losses import GANLoss, L1Loss, PSNRLoss
 from .model import EDSR, ESPCN, SRCNN, SRDN, NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
 from .optim import Adam
 
-__all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasParams", "set_requires_grad"]
+__all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasSRCConst", "CasSRCLAB", "CasSRCConstLAB", "CasParams",
+           "set_requires_grad"]
 
 
 def set_requires_grad(nets, requires_grad=False):
@@ -244,7 +245,8 @@ class CasSRC:
         sr = MODEL_REGISTRY[opt.SRModel]
         cm = MODEL_REGISTRY[opt.CModel]
         self.netG_A2C = sr(1, 1, opt.up).to(opt.device)
-        self.netG_C2B = (cm(1, 3, 1) if cm is RDDBNet else cm(1, 3)).to(opt.device)
+        co = getattr(self, "_c_out", 3)
+        self.netG_C2B = (cm(1, co, 1) if cm is RDDBNet else cm(1, co)).to(opt.device)
         self.criterionSR, self.criterionC, self.criterionPSNR = L1Loss(), L1Loss(), PSNRLoss()
         self.optimizer_G = Adam(self.netG_A2C.parameters(), lr=opt.lr)
         self.optimizer_D = Adam(self.netG_C2B.parameters(), lr=opt.lr)
@@ -322,3 +324,49 @@ class CasSRC:
         device scalars are only synchronised when the log line is produced)."""
         m = lambda xs: float(torch.stack(list(xs)).mean()) if xs else float("nan")
         return {"loss_SR": m(self.loss_sr), "psnr_SR": m(self.psnr_sr), "loss_C": m(self.loss_c), "psnr_C": m(self.psnr_c)}
+
+
+class CasSRCConst(CasSRC):
+    """reference src/trainCasConst.py: the SR network keeps the resolution (use a size-preserving --SRModel such as SRCNN or
+    SRDN); its training input is the gray target blurred by bilinear /up then x up (:89-92); transfer() feeds realA as is (:103-105)."""
+
+    def forwardSR(self, realB):
+        self.real_B = realB
+        self.real_BC = ops.rgb_to_gray(realB)
+        self.real_BA = ops.bilinear_up(ops.bilinear_down(self.real_BC, self.opt.up), self.opt.up)
+        self.fake_BC = self.netG_A2C(self.real_BA)
+
+    def transfer(self, realA):
+        self.real_A = realA
+        self.netG_A2C.eval()
+        self.netG_C2B.eval()
+        with torch.no_grad():
+            self.fake_AC = self.netG_A2C(self.real_A)
+            self.fake_AB = self.netG_C2B(self.fake_AC)
+
+
+class _LabMixin:
+    """reference src/trainCasLAB.py / trainCasConstLAB.py: targets arrive as normalised LAB [B,3,H,W]; the SR branch works on L
+    (channel 0), the colouriser maps L to the two ab channels (CModel(1, 2), :31; real_B = ab, real_BC = L, :83-84)."""
+    _c_out = 2
+
+    def _split(self, realB):
+        self.real_B = realB[:, 1:, :, :].contiguous()
+        self.real_BC = realB[:, :1, :, :].contiguous()
+
+
+class CasSRCLAB(_LabMixin, CasSRC):
+    def forwardSR(self, realB):
+        self._split(realB)
+        self.real_BA = ops.bilinear_down(self.real_BC, self.opt.up)
+        self.fake_BC = self.netG_A2C(self.real_BA)
+
+
+class CasSRCConstLAB(_LabMixin, CasSRCConst):
+    """BASELINE.json configs[3] ("cascade-const LAB") surface: src/trainCasConstLAB.py."""
+
+    def forwardSR(self, realB):
+        self._split(realB)
+        self.real_BA = ops.bilinear_up(ops.bilinear_down(self.real_BC, self.opt.up), self.opt.up)
+        self.fake_BC = self.netG_A2C(self.real_BA)
+

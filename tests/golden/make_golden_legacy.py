@@ -117,6 +117,30 @@ def cas_default():
     print("cas_default", cas.loss_sr, cas.loss_c, cas.psnr_sr, cas.psnr_c)
 
 
+def cas_variants():
+    """One-to-two optimisation steps of the cascade variants (src/trainCasConst.py, trainCasLAB.py, trainCasConstLAB.py) with a
+    size-preserving SR network where the script needs one; losses / PSNRs / outputs only (weights are reproduced by seed)."""
+    import importlib
+    for tag, modname, sr, shape_a in (("cas_const", "trainCasConst", "SRCNN", (1, 1, 48, 64)), ("cas_lab", "trainCasLAB", "ESPCN", (1, 1, 48, 64)),
+                                      ("cas_constlab", "trainCasConstLAB", "SRDN", (2, 1, 32, 48))):
+        mod = importlib.import_module(modname)
+
+        class Opt:
+            device = torch.device("cpu"); lr = 1e-4; batch_size = 1; num_works = 0
+            num_epochs = 50; matrix = 0; lr_policy = "cosine"; up = 2
+            SRModel = sr; CModel = "ResDeconv"
+        torch.manual_seed(0)
+        cas = mod.CasSRC(Opt)
+        cas.init_log()
+        realA = torch.rand(*shape_a)
+        realB = torch.rand(shape_a[0], 3, shape_a[2], shape_a[3])
+        for _ in range(2):
+            cas.optimize_parameters(realA, realB)
+        np.savez(os.path.join(OUT, f"{tag}.npz"), realA=npy(realA), realB=npy(realB), loss_sr=np.array(cas.loss_sr), loss_c=np.array(cas.loss_c),
+                 psnr_sr=np.array(cas.psnr_sr), psnr_c=np.array(cas.psnr_c), real_BA=npy(cas.real_BA), fake_BC=npy(cas.fake_BC), fake_AC=npy(cas.fake_AC))
+        print(tag, cas.loss_sr, cas.loss_c)
+
+
 def metrics_golden():
     """Reference src/metrics.py (AE, MSE, PSNR, SSIM) on three value ranges that select SSIM's three dynamic ranges."""
     import metrics as ref
@@ -141,3 +165,4 @@ if __name__ == "__main__":
     metrics_golden()
     edsr_golden()
     srdn_golden()
+    cas_variants()

@@ -227,3 +227,25 @@ def test_evaluate_cascade_loop():
     perf, (fake_AB, fake_BB) = M.evaluate_cascade(sr, cn, batches, up=2)
     assert set(perf) == {"MSE", "PSNR", "AE", "SSIM"} and all(np.isfinite(v) for v in perf.values())
     assert fake_AB.shape == fake_BB.shape == (1, 3, 64, 64)
+
+
+@pytest.mark.parametrize("tag,cls,sr", [("cas_const", "CasSRCConst", "SRCNN"), ("cas_lab", "CasSRCLAB", "ESPCN"), ("cas_constlab", "CasSRCConstLAB", "SRDN")])
+def test_cascade_variants_golden(tag, cls, sr):
+    """The cascade variants of the reference (src/trainCasConst.py, trainCasLAB.py, trainCasConstLAB.py -- the last one is the
+    surface of BASELINE configs[3]) for two steps: blur by bilinear down-up, L / ab split, CModel(1, 2); networks seeded like the
+    reference run, every logged loss and PSNR and the SR outputs compared."""
+    from srcgan_amd import train as T
+    g = load_golden(tag)
+    opt = T.CasParams(device="cuda", SRModel=sr, CModel="ResDeconv", up=2)
+    torch.manual_seed(0)
+    m = getattr(T, cls)(opt)
+    realA, realB = torch.from_numpy(g["realA"]).cuda(), torch.from_numpy(g["realB"]).cuda()
+    for _ in range(2):
+        m.optimize_parameters(realA, realB)
+    assert rel_err(m.real_BA.cpu(), g["real_BA"]) < 1e-5
+    for mine, ref in ((m.loss_sr, g["loss_sr"]), (m.loss_c, g["loss_c"])):
+        assert np.allclose([float(v) for v in mine], ref, rtol=1e-3, atol=1e-6), (mine, ref)
+    for mine, ref in ((m.psnr_sr, g["psnr_sr"]), (m.psnr_c, g["psnr_c"])):
+        assert np.allclose([float(v) for v in mine], ref, rtol=0, atol=3e-3), (mine, ref)
+    assert rel_err(m.fake_BC.cpu(), g["fake_BC"]) < 3e-3
+    assert rel_err(m.fake_AC.cpu(), g["fake_AC"]) < 3e-3
