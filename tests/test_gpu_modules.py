@@ -353,3 +353,24 @@ def test_srdn_golden_f32(tag):
             assert p.grad is None, k
         else:
             assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+
+
+def test_stacked_generators_x8_vs_oracle():
+    """BASELINE configs[4] shape in miniature: a x4 generator feeding a x2 generator (3x16x12 -> 3x128x96); the second network's
+    input gradient flows into the first through autograd (srcgan_rddbnet_backward's dx).  fp32 against the oracle."""
+    from srcgan_amd import RDDBNet, L1Loss
+    s1 = oracle.rddbnet_state(3, 3, 4, 16, 1, 8, seed=11)
+    s2 = oracle.rddbnet_state(3, 3, 2, 16, 1, 8, seed=12)
+    g1, g2 = _load(RDDBNet(3, 3, 4, nf=16, nb=1, gc=8, dtype="fp32"), s1), _load(RDDBNet(3, 3, 2, nf=16, nb=1, gc=8, dtype="fp32"), s2)
+    torch.manual_seed(13)
+    x, t = torch.rand(2, 3, 16, 12), torch.rand(2, 3, 128, 96)
+    r1 = {k: v.clone().requires_grad_(True) for k, v in s1.items()}
+    r2 = {k: v.clone().requires_grad_(True) for k, v in s2.items()}
+    yr = oracle.rddbnet_forward(r2, oracle.rddbnet_forward(r1, x, 4), 2)
+    oracle.l1_loss(yr, t).backward()
+    y = g2(g1(x.cuda()))
+    L1Loss()(y, t.cuda()).backward()
+    assert rel_err(y.cpu(), yr) < F32_TOL
+    for net, ref in ((g1, r1), (g2, r2)):
+        for k, p in net.named_parameters():
+            assert rel_err(p.grad.cpu(), ref[k].grad) < F32_TOL, k
