@@ -95,6 +95,8 @@ typedef struct srcgan_conv_desc {
     /* plane strides in BYTES for the blocked layout (0 = interleaved NHWC): channel c of pixel q lives at
      * q*cs*esz + (c/KCE)*plane + (c%KCE)*esz with KCE = 64/esz channels; blocked tensors use cs = KCE. */
     long x_plane, y_plane, r1_plane, r2_plane, mz_plane;
+    int rev_batch;     /* walk the images in reverse order (3x3 s1 kernel): consecutive layers alternate so that a layer starts on
+                          the data its predecessor touched last (Infinity Cache reuse when a layer's footprint exceeds 256 MB) */
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 

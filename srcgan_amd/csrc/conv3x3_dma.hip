@@ -307,7 +307,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
         auto issue = [&](int c, int stage) __attribute__((always_inline)) {             // chunk c of the unit (uct, utx, uty, ub)
             char* lh = smem + stage * SBYTES;
             char* lw = lh + HBYTES;
-            const long org = ((long)ub * p.H + (uty * TH - p.pad_y)) * p.W + (utx * TW - p.pad_x);     // tile origin, pixels
+            const long org = ((long)(p.rev ? p.B - 1 - ub : ub) * p.H + (uty * TH - p.pad_y)) * p.W + (utx * TW - p.pad_x);     // tile origin, pixels
             const char* bx = xb0 + org * p.xpix + c * cstride;
             const char* bw = (const char*)p.wp + ((size_t)uct * p.nchunk + c) * NTAP * COT * 64;
             const int cls = (uty == 0 ? 0 : uty == p.tiles_y - 1 ? 2 : 1) * 3 + (utx == 0 ? 0 : utx == p.tiles_x - 1 ? 2 : 1);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     for (int u = u0; u < u_hi; u += gw) {
         const int cct = u % p.ctiles; int t = u / p.ctiles;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; const int cb = t / p.tiles_y;
+        const int ty = t % p.tiles_y; const int cb = p.rev ? p.B - 1 - t / p.tiles_y : t / p.tiles_y;
         const int coy0 = ty * TH, cox0 = tx * TW;
         f32x16 acc[MT][PT];
 #pragma unroll

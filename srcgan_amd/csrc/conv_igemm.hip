@@ -272,6 +272,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * esz; p.yplane = pl(d->y_plane);
     p.r1pix = (long)d->r1_cs * esz; p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
     p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
+    p.rev = d->rev_batch;
     p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
     p.act = d->act;
     const int kce = 64 / esz;

@@ -17,6 +17,7 @@ struct ConvP {
     float alpha, beta1, beta2, slope, mslope;
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
+    int rev;      // images are walked last to first
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
 };

@@ -44,7 +44,13 @@ struct Conv {
     Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_plane = r.plane; d.r2_cend = cend; d.beta2 = beta; return *this; }
     Conv& lrelu() { d.act = 1; return *this; }
     Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
-    int run(void* st) { return srcgan_conv_igemm(&d, st); }
+    // consecutive 3x3 s1 launches walk the batch in alternating directions (SRCGAN_NO_ZIGZAG=1 disables): see srcgan_conv_desc.rev_batch
+    int run(void* st) {
+        static const bool zig = getenv("SRCGAN_NO_ZIGZAG") == nullptr;
+        static int flip = 0;
+        if (zig && d.kh == 3 && d.kw == 3 && d.stride == 1) { d.rev_batch = flip; flip ^= 1; }
+        return srcgan_conv_igemm(&d, st);
+    }
 };
 
 // canonical weight layouts
