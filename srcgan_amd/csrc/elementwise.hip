@@ -316,23 +316,34 @@ __global__ __launch_bounds__(256) void col_reduce_vec_k(const T* __restrict__ a,
     }
 }
 
-// one block per 64 channels; 4 block-lanes split the partials, fixed order
+// one block per 8 channels; 32 block-lanes split the partials (4 loads in flight each), fixed order
 __global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ partial, int nblk, int C, float scale,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ float red[2][4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C)
-        for (int b = py; b < nblk; b += 4) {
-            s0 += partial[(size_t)b * C + c];
-            if (out1) s1 += partial[((size_t)nblk + b) * C + c];
+    __shared__ float red[2][32][8];
+    const int cx = threadIdx.x & 7, py = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        int b = py;
+        for (; b + 96 < nblk; b += 128) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0[u] += partial[(size_t)(b + 32 * u) * C + c];
+                if (out1) s1[u] += partial[((size_t)nblk + b + 32 * u) * C + c];
+            }
         }
-    red[0][py][cx] = s0; red[1][py][cx] = s1;
+        for (; b < nblk; b += 32) {
+            s0[0] += partial[(size_t)b * C + c];
+            if (out1) s1[0] += partial[((size_t)nblk + b) * C + c];
+        }
+    }
+    red[0][py][cx] = (s0[0] + s0[1]) + (s0[2] + s0[3]); red[1][py][cx] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
     __syncthreads();
     if (py == 0 && c < C) {
-        out0[c] = ((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx])) * scale;
-        if (out1) out1[c] = ((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx])) * scale;
+        float t0 = 0.f, t1 = 0.f;
+        for (int q = 0; q < 32; ++q) { t0 += red[0][q][cx]; t1 += red[1][q][cx]; }
+        out0[c] = t0 * scale;
+        if (out1) out1[c] = t1 * scale;
     }
 }
 
@@ -366,7 +377,7 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
         else hipLaunchKernelGGL((col_reduce_k<T, 2>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
     });
     SG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 64)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
+    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
     SG_LAUNCH_CHECK();
     return 0;
 }

@@ -385,8 +385,18 @@ __global__ __launch_bounds__(256) void wgrad_dense_reduce_k(const WdRedP p) {
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * 64 + el;
     float s = 0.f;
-    if (e < per_split)
-        for (int sp = sl; sp < p.nsplit; sp += 4) s += p.slab[(size_t)sp * per_split + e];
+    if (e < per_split) {                      // four loads in flight per lane; the order stays fixed
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int sp = sl;
+        for (; sp + 12 < p.nsplit; sp += 16) {
+            a0 += p.slab[(size_t)sp * per_split + e];
+            a1 += p.slab[(size_t)(sp + 4) * per_split + e];
+            a2 += p.slab[(size_t)(sp + 8) * per_split + e];
+            a3 += p.slab[(size_t)(sp + 12) * per_split + e];
+        }
+        for (; sp < p.nsplit; sp += 4) a0 += p.slab[(size_t)sp * per_split + e];
+        s = (a0 + a1) + (a2 + a3);
+    }
     red[sl][el] = s;
     __syncthreads();
     if (sl != 0 || e >= per_split) return;
