@@ -97,6 +97,12 @@ typedef struct srcgan_conv_desc {
     long x_plane, y_plane, r1_plane, r2_plane, mz_plane;
     int rev_batch;     /* walk the images in reverse order (3x3 s1 kernel): consecutive layers alternate so that a layer starts on
                           the data its predecessor touched last (Infinity Cache reuse when a layer's footprint exceeds 256 MB) */
+    /* LeakyReLU sign masks, one bit per channel instead of re-reading the 2-byte activation in the backward pass (3x3 s1 bf16,
+     * Cout == 32, os == 1, blocked input: the dense-block convs).  u32 per output pixel (b, oy, ox), bit c = output channel c.
+     *   sign_out: written by a forward conv with act != 0 (bit = activation output > 0)
+     *   sign_in : read instead of mz:  v *= bit ? 1 : mslope
+     * A descriptor that sets either and does not meet the conditions is refused (no silent fallback). */
+    void* sign_out; const void* sign_in;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# per-kernel time of the dense wgrad microbenchmark for library variants (scripts/build_variant.sh): usage wd_variants.sh <name>...
+# ("base" = the in-tree library).  Output: gpurun_out/wd_variants.txt
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+: > $OUT/wd_variants.txt
+for v in "$@"; do
+  if [ "$v" = base ]; then unset SRCGAN_AMD_LIB; else export SRCGAN_AMD_LIB=$ROOT/srcgan_amd/lib/variants/$v.so; fi
+  rm -rf $OUT/prof_wdv
+  MB_BLOCKED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_wdv -- python $ROOT/scripts/microbench_wgrad_dense.py > $OUT/prof_wdv.log 2>&1 || exit 1
+  python - "$v" >> $OUT/wd_variants.txt <<PY
+import csv, glob, sys
+f = glob.glob("$OUT/prof_wdv/**/*kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "wgrad_dense_fast" in r["Name"]:
+        print(f"{sys.argv[1]:10s} {r['Name'][:50]:50s} avg {float(r['AverageNs'])/1e3:8.1f} us")
+PY
+done
+rm -rf $OUT/prof_wdv
+cat $OUT/wd_variants.txt

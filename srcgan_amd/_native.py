@@ -54,7 +54,8 @@ class ConvDesc(C.Structure):
                 ("mz_cs", C.c_int), ("mz_coff", C.c_int), ("mz_c0", C.c_int),
                 ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("slope", C.c_float), ("mslope", C.c_float),
                 ("act", C.c_int),
-                ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long), ("rev_batch", C.c_int)]
+                ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long), ("rev_batch", C.c_int),
+                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -584,6 +584,8 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
     // the loader-specialised kernel needs a uniform K-chunk stride and 31-bit per-image offsets
     const bool ls_ok = (p.xplane == 0 || p.xcoff % DT<T>::KCE == 0) && (p.Cin % DT<T>::KCE == 0 || p.nchunk == 1) &&
                        p.pad_y == 1 && p.pad_x == 1 && p.Cout <= 1024 && (18.0 * p.W + 34.0) * (double)p.xpix < 2147483647.0;
+    if (p.sgn_in || p.sgn_out)
+        SG_REQUIRE(ls_ok && cfg != 'a' && sizeof(T) == 2 && p.Cout == 32, "conv3x3: sign masks are only handled by the loader-specialised bf16 kernel (Cout == 32)");
     if (!ls_ok) cfg = 'a';
     if (p.Cout <= 32) {
         if (cfg == 'a') return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
@@ -595,14 +597,19 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
             static const bool no_wres = getenv("SRCGAN_NO_WRES") != nullptr;
             // resident weights: two 40 KiB halo stages + nchunk * 18 KiB + bias within 160 KiB
             // epilogue operand set: Cout <= 32 convs are the dense-block forward (none) and its gradient slices (mz)
-            const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0);
+            const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0) | (p.sgn_in ? 8 : 0) | (p.sgn_out ? 16 : 0);
+            SG_REQUIRE(em < 8 || em == 8 || em == 16, "conv3x3: a sign mask cannot be combined with other epilogue operands");
             if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) {
                 if (em == 0) return launch_ls<T, 1, 8, true, 0>(p, 1, st);
                 if (em == 4) return launch_ls<T, 1, 8, true, 4>(p, 1, st);
+                if (em == 8) return launch_ls<T, 1, 8, true, 8>(p, 1, st);
+                if (em == 16) return launch_ls<T, 1, 8, true, 16>(p, 1, st);
                 return launch_ls<T, 1, 8, true, 7>(p, 1, st);
             }
             if (em == 0) return launch_ls<T, 1, SG_NLW1, false, 0>(p, 1, st);
             if (em == 4) return launch_ls<T, 1, SG_NLW1, false, 4>(p, 1, st);
+            if (em == 8) return launch_ls<T, 1, SG_NLW1, false, 8>(p, 1, st);
+            if (em == 16) return launch_ls<T, 1, SG_NLW1, false, 16>(p, 1, st);
             return launch_ls<T, 1, SG_NLW1, false, 7>(p, 1, st);
         }
     }

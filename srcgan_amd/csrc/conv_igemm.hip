@@ -273,6 +273,11 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.r1pix = (long)d->r1_cs * esz; p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
     p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
     p.rev = d->rev_batch;
+    p.sgn_out = (unsigned char*)d->sign_out; p.sgn_in = (const unsigned char*)d->sign_in;
+    if (d->sign_out || d->sign_in)
+        SG_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dtype == SRCGAN_BF16 && d->Cout == 32 && d->os == 1 && d->oa == 0 && d->ob == 0 &&
+                   d->YH == d->OH && d->YW == d->OW && d->x_plane && !(d->sign_in && d->mz) && (!d->sign_out || d->act),
+                   "srcgan_conv_igemm: sign masks need a 3x3 s1 bf16 conv with Cout == 32 on a blocked input, unscaled output (and act for sign_out, no mz beside sign_in)");
     p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
     p.act = d->act;
     const int kce = 64 / esz;

@@ -18,6 +18,7 @@ struct ConvP {
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
     int rev;      // images are walked last to first
+    unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
 };
@@ -240,7 +241,8 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x
 //  * the residual (r1) and activation-mask (mz) operands of ALL passes of a row are requested before the row's
 //    accumulators go through the LDS transposition, so one memory latency is exposed per row, not one per pass.
 // b, ct, oy0, ox0 must be wave-uniform.
-// EM: which optional operands this instantiation can take (1 = r1, 2 = r2, 4 = mz); the others compile away, with
+// EM: which optional operands this instantiation can take (1 = r1, 2 = r2, 4 = mz, 8 = sign mask read, 16 = sign mask write;
+// the masks need MT == 1, 8 channels per lane and os == 1: byte (c0 / 8) of the pixel's u32); the others compile away, with
 // their addressing and the scalar registers it pins (the all-operand form spills ~100 SGPRs and runs ~1000 instructions).
 template <typename T, int MT, int PT, int EM = 7>
 __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32x16 (&acc)[MT][PT], char* lds_wave, const char* lds_bias,
@@ -266,6 +268,9 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
     const long l1 = use_r1 ? lstep * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane) : 0;
     const long l2 = use_r2 ? lstep * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane) : 0;
     const long lm = use_mz ? lstep * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane) : 0;
+    constexpr bool SGI = (EM & 8) != 0, SGO = (EM & 16) != 0;
+    static_assert(!(SGI || SGO) || (MT == 1 && EPP == 8), "sign masks: 32 output channels, 8 per lane");
+    const long ls = (long)lx * 4 + (c0 >> 3);          // mask byte of this lane's 8 channels
     const int xrem = p.OW - ox0 - lx;                // pass k is in range iff k * PPP < xrem
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
@@ -275,6 +280,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
         const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
         const long pstep = (long)PPP * p.os;
         vecT r1v[NPF], mzv[NPF];
+        unsigned sgv[NPF];
         if (PF) {
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
@@ -282,6 +288,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
                 const long px = rowpix + pass * pstep;
                 if (use_r1 && ok) r1v[pass % NPF] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
                 if (use_mz && ok) mzv[pass % NPF] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
+                if (SGI && ok) sgv[pass % NPF] = p.sgn_in[px * 4 + ls];
             }
         }
 #pragma unroll
@@ -304,6 +311,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
             if (!PF) {
                 if (use_r1) r1v[0] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
                 if (use_mz) mzv[0] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
+                if (SGI) sgv[0] = p.sgn_in[px * 4 + ls];
             }
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
@@ -319,6 +327,15 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
             if (use_mz) {
 #pragma unroll
                 for (int i = 0; i < EPP; ++i) v[i] *= (to_f(mzv[pass % NPF][i]) > 0.f ? 1.f : p.mslope); }
+            if (SGI) {
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) v[i] *= ((sgv[pass % NPF] >> i) & 1u) ? 1.f : p.mslope; }
+            if (SGO) {
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) m |= (v[i] > 0.f ? 1u : 0u) << i;
+                p.sgn_out[px * 4 + ls] = (unsigned char)m;
+            }
             vecT o;
 #pragma unroll
             for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);

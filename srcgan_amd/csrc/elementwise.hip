@@ -129,9 +129,48 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src,
     }
 }
 
+// Image-channel fast paths (C <= 8 channels in 8-channel bf16 records, HW % 4 == 0): a thread moves 4 consecutive
+// pixels -- one float4 per plane on the NCHW side, 4 x 16 B = 64 contiguous bytes on the NHWC side.
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_k(const float* __restrict__ src, __bf16* __restrict__ dst, int C, long HW, long nquad) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 rec8;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
+        const long b = q / (HW / 4), p0 = (q % (HW / 4)) * 4;
+        float4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[c] = c < C ? *(const float4*)(src + ((size_t)b * C + c) * HW + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rec8 r[4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { r[0][c] = from_f<__bf16>(v[c].x); r[1][c] = from_f<__bf16>(v[c].y); r[2][c] = from_f<__bf16>(v[c].z); r[3][c] = from_f<__bf16>(v[c].w); }
+        rec8* o = (rec8*)(dst + ((size_t)b * HW + p0) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = r[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc8_to_nchw_k(const __bf16* __restrict__ src, float* __restrict__ dst, int C, long HW, long nquad) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 rec8;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
+        const long b = q / (HW / 4), p0 = (q % (HW / 4)) * 4;
+        const rec8* in = (const rec8*)(src + ((size_t)b * HW + p0) * 8);
+        rec8 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = in[j];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) *(float4*)(dst + ((size_t)b * C + c) * HW + p0) = make_float4(to_f(r[0][c]), to_f(r[1][c]), to_f(r[2][c]), to_f(r[3][c]));
+    }
+}
+
 extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cs, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "srcgan_nchw_f32_to_nhwc: bad arguments");
     const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
+    if (dtype == SRCGAN_BF16 && cs == 8 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+        const long nq = (long)B * (HW / 4);
+        hipLaunchKernelGGL(nchw_to_nhwc8_k, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, C, HW, nq);
+        SG_LAUNCH_CHECK();
+        return 0;
+    }
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_nhwc_k<T>, dim3(ew_blocks(np, 1)), dim3(256), 0, (hipStream_t)stream,
                                              src, (T*)dst, C, HW, cs, np));
     SG_LAUNCH_CHECK();
@@ -141,6 +180,12 @@ extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C
 extern "C" int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int cs, int coff, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C + coff, "srcgan_nhwc_to_nchw_f32: bad arguments");
     const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
+    if (dtype == SRCGAN_BF16 && cs == 8 && coff == 0 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+        const long nq = (long)B * (HW / 4);
+        hipLaunchKernelGGL(nhwc8_to_nchw_k, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst, C, HW, nq);
+        SG_LAUNCH_CHECK();
+        return 0;
+    }
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nhwc_to_nchw_k<T>, dim3(ew_blocks(np, 1)), dim3(256), 0, (hipStream_t)stream,
                                              (const T*)src, dst, C, HW, cs, coff, np));
     SG_LAUNCH_CHECK();

@@ -43,6 +43,8 @@ struct Conv {
     Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_plane = r.plane; d.r1_cend = cend; d.beta1 = beta; return *this; }
     Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_plane = r.plane; d.r2_cend = cend; d.beta2 = beta; return *this; }
     Conv& lrelu() { d.act = 1; return *this; }
+    Conv& sign_out(void* m) { d.sign_out = m; return *this; }                  // write / read the LeakyReLU sign mask (u32 per pixel)
+    Conv& sign_in(const void* m) { d.sign_in = m; return *this; }
     Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
     // consecutive 3x3 s1 launches walk the batch in alternating directions (SRCGAN_NO_ZIGZAG=1 disables): see srcgan_conv_desc.rev_batch
     int run(void* st) {
@@ -124,6 +126,7 @@ struct PackList {
 struct RddbPlan {
     int dtype, esz, nf, gc, nb, C, nst, ndn, kce, nplane; long plane_bytes;
     int B, H, W;           // input
+    size_t bm; long bm_bytes;   // sign masks of a dense buffer's four LeakyReLU slices: offset inside the buffer, bytes per slice (0 = not used)
     int Ht, Wt;            // trunk resolution
     int HO, WO;            // output resolution
     int in_cs, out_cs;
@@ -179,7 +182,11 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     // dense buffers use the blocked layout [plane = 64-byte channel chunk][pixel][64 B]: every operand fetch of the 3x3 kernel
     // and of the dense wgrad is then >= 1 KiB contiguous (64-byte pieces at a 384-byte pixel stride ran at half rate)
     P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
-    P.szA = align_up((size_t)P.nplane * P.plane_bytes, 256);
+    // one bit per element for LeakyReLU' (instead of re-reading the activation in the backward pass): bf16, 32-channel slices
+    static const bool no_sign = getenv("SRCGAN_NO_SIGNMASK") != nullptr || getenv("SRCGAN_DMA_CFG") != nullptr;
+    P.bm_bytes = (!no_sign && c->dtype == SRCGAN_BF16 && c->gc == 32 && c->nf % 32 == 0 && c->legacy != 2) ? (long)B * P.Ht * P.Wt * 4 : 0;
+    P.bm = align_up((size_t)P.nplane * P.plane_bytes, 256);
+    P.szA = align_up(P.bm + 4 * (size_t)P.bm_bytes, 256);
     P.A = b.take(P.szA * (c->legacy == 2 ? 1 : 3 * P.nrr));        // legacy RDDBNet discards its trunk: one buffer holds conv_first's output
     P.T = b.take(B * P.Ht * P.Wt * c->nf * e);
     for (int s = 0; s <= ((c->legacy == 1 || c->legacy == 2) ? 0 : P.nst); ++s) P.U[s] = b.take(B * (P.Ht << s) * (P.Wt << s) * c->nf * e);
@@ -340,8 +347,10 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
             TRef A = Abuf(r);
             for (int k = 0; k < 4; ++k) {
                 const int cin = nf + k * gc;
-                SG_TRY(Conv(dt, 3, 3, 1).in(A, B, H, W, cin).w(wp + P.w_rdb_f[r * 5 + k], params[P.prdb(r) + k * 2 + 1])
-                           .out(sl(A, cin), H, W, gc).pad(1, 1).lrelu().run(st));
+                Conv cv(dt, 3, 3, 1);
+                cv.in(A, B, H, W, cin).w(wp + P.w_rdb_f[r * 5 + k], params[P.prdb(r) + k * 2 + 1]).out(sl(A, cin), H, W, gc).pad(1, 1).lrelu();
+                if (P.bm_bytes) cv.sign_out((char*)A.p + P.bm + (size_t)k * P.bm_bytes);
+                SG_TRY(cv.run(st));
             }
             // conv5 + residual(s) -> channels [0,nf) of the next dense buffer (or the trunk output)
             const bool last = (r == P.nrr * 3 - 1);
@@ -572,7 +581,9 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                 cv.in(Gd, B, H, W, ktot).w(wp + P.w_rdb_d[r * 5 + j]).pad(1, 1);
                 if (j > 0) {
                     // slice x_j is a LeakyReLU output: multiply by its derivative -> this IS dy_j
-                    cv.out(sl(Gd, nf + (4 - j) * gc), H, W, gc).mask(sl(A, nf + (j - 1) * gc), 0);
+                    cv.out(sl(Gd, nf + (4 - j) * gc), H, W, gc);
+                    if (P.bm_bytes) { cv.sign_in((const char*)A.p + P.bm + (size_t)(j - 1) * P.bm_bytes); cv.d.mslope = 0.2f; }
+                    else cv.mask(sl(A, nf + (j - 1) * gc), 0);
                 } else {
                     cv.out(nxt, H, W, nf).res1(Gd, nf, bres);
                     if (j3 == 0) cv.res2(nxt, nf, 1.f);     // RRDB skip; nxt == Pg(0) still holds d(out_rrdb): in-place, same element

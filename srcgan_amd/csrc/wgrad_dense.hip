@@ -192,6 +192,15 @@ __device__ __forceinline__ void wd_dma16(const void* base, int voff, int soff, w
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(dst), "s"(soff) : "memory");
 }
 
+// Timing experiments (wrong results; scripts/wd_variants.sh): 1 no DMA after the first tile, 2 no MFMA, 4 no input-fragment
+// reads in the loop, 8 every piece out of range (issue cost without memory traffic).  Round-1 findings at the bench shape
+// (random data, so lower clocks than in training): 452 us as built; 316 us without the DMA stream; 197 us without MFMAs;
+// 283 us with the DMAs issued but out of range -- the issue itself is free, the loss is the memory path pushing back on the
+// issuing (MFMA) waves; a step is 4864 matrix-pipe cycles + the per-wave stall time, because the older wave of each SIMD
+// pair takes the pipe first and the younger one finishes alone (trace: waves 4-7 reach the barrier ~1.2 us after 0-3).
+#ifndef SG_WD_EXP
+#define SG_WD_EXP 0
+#endif
 template <int MT, int NT, int TH>
 __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) {
     using T = __bf16;
@@ -282,7 +291,8 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
     auto piece = [&](int it, int stage) __attribute__((always_inline)) {
         const int pi = it * NW + wave;
         if (IPW * NW != NPIECE && pi >= NPIECE) return;
-        const int v = ((clm[it / 8] >> (4 * (it % 8))) & 15u) ? OOB : voff[it];
+        int v = ((clm[it / 8] >> (4 * (it % 8))) & 15u) ? OOB : voff[it];
+        if (SG_WD_EXP & 8) v = OOB;
         wd_dma16(pi < MT * DPP ? dyo : xo, v, soff[it], (wd_lptr_t)(smem + stage * SBYTES + pi * 1024));
     };
 
@@ -341,8 +351,8 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
         for (int G = 0; G < PD; ++G) read_b(G);
 #pragma unroll
         for (int G = 0; G < NGRP; ++G) {
-            if (G + PD < NGRP) read_b(G + PD);
-            if (more) {                                  // next tile's pieces ride in the shadow of this tile's MFMAs
+            if (G + PD < NGRP && !(SG_WD_EXP & 4)) read_b(G + PD);
+            if (more && !(SG_WD_EXP & 1)) {              // next tile's pieces ride in the shadow of this tile's MFMAs
 #pragma unroll
                 for (int j = 0; j < PPK; ++j)
                     if (PPK * G + j < IPW) piece(PPK * G + j, stage ^ 1);
@@ -353,7 +363,8 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
             for (int py = 0; py < TH; ++py) {
                 const int ky = i2 - py;
                 if (ky < 0 || ky > 2) continue;
-                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx], 0, 0, 0);
+                if (!(SG_WD_EXP & 2)) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx], 0, 0, 0);
+                else asm volatile("" :: "v"(fa[py][xh]), "v"(fb[G % (PD + 1)]));
             }
             // bias pseudo-tap: one MFMA per gradient fragment, placed in the single-MFMA groups of the first/last input row
             if (do_bias && kx == 0 && (i2 == 0 || i2 == IHT - 1))

@@ -82,9 +82,11 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
                r2: Optional[torch.Tensor] = None, r2_coff: int = 0, r2_cend: int = 0, beta2: float = 0.0,
                mz: Optional[torch.Tensor] = None, mz_coff: int = 0, mz_c0: int = 0, mslope: float = 0.2,
                os: int = 1, oa: int = 0, ob: int = 0, x_plane: int = 0, y_plane: int = 0, r1_plane: int = 0, r2_plane: int = 0,
-               mz_plane: int = 0, shape: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+               mz_plane: int = 0, shape: Optional[Tuple[int, int, int]] = None, sign_out: Optional[torch.Tensor] = None,
+               sign_in: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x, y, r1, r2, mz: NHWC tensors [B,H,W,cs] of the compute dtype.  Writes into y (returned).
-    Blocked-layout tensors ([planes,B,H,W,KCE], see make_blocked) pass *_plane = plane stride in bytes and shape=(B,H,W)."""
+    Blocked-layout tensors ([planes,B,H,W,KCE], see make_blocked) pass *_plane = plane stride in bytes and shape=(B,H,W).
+    sign_out / sign_in: int32 [B,OH,OW] LeakyReLU sign masks (bit c = channel c), see srcgan_conv_desc in include/srcgan_amd.h."""
     N.require_cuda(x, "conv_igemm")
     d = N.ConvDesc()
     if shape is not None:
@@ -108,6 +110,10 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
         d.r2, d.r2_cs, d.r2_coff, d.r2_cend, d.beta2 = r2.data_ptr(), r2.shape[-1], r2_coff, r2_cend, beta2
     if mz is not None:
         d.mz, d.mz_cs, d.mz_coff, d.mz_c0 = mz.data_ptr(), mz.shape[-1], mz_coff, mz_c0
+    if sign_out is not None:
+        d.sign_out = sign_out.data_ptr()
+    if sign_in is not None:
+        d.sign_in = sign_in.data_ptr()
     d.alpha, d.slope, d.mslope, d.act = alpha, slope, mslope, int(act)
     d.x_plane, d.y_plane, d.r1_plane, d.r2_plane, d.mz_plane = x_plane, y_plane, r1_plane, r2_plane, mz_plane
     N.check(N.lib().srcgan_conv_igemm(C.byref(d), N.stream_ptr(x.device)), "srcgan_conv_igemm")

@@ -323,6 +323,40 @@ def test_conv3x3_blocked_layout(ops, dt, cin, cout, hw):
     assert rel_err(ops.to_nchw(y2).cpu(), ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("cin,hw", [(64, (16, 32)), (96, (33, 70)), (160, (16, 64))])
+def test_conv3x3_sign_masks(ops, cin, hw):
+    """LeakyReLU sign masks (one bit per channel, u32 per pixel) of the dense-block convs: the forward conv writes them, the
+    gradient-slice conv reads them instead of the activation -- bit-identical to the mz operand form; misuse is refused."""
+    torch.manual_seed(23)
+    H, W = hw
+    B, Cc, cout, dt = 2, 192, 32, "bf16"
+    buf = torch.rand(B, Cc, H, W) - 0.5
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    b = torch.randn(cout) * 0.1
+    wp = ops.pack_conv2d_fwd(w.cuda(), dt)
+    db, pl = ops.make_blocked(_nhwc(ops, buf, Cc, dt))
+    sign = torch.zeros(B, H, W, dtype=torch.int32, device="cuda")
+    ops.conv_igemm(db, wp, db, kh=3, kw=3, Cin=cin, Cout=cout, y_coff=cin, pad=(1, 1), bias=b.cuda(), act=True,
+                   x_plane=pl, y_plane=pl, shape=(B, H, W), sign_out=sign)
+    act = ops.to_nchw(ops.from_blocked(db, Cc), cout, cin)                   # [B,32,H,W] f32, the stored activation
+    bits = ((sign.unsqueeze(1) >> torch.arange(32, device="cuda").view(1, 32, 1, 1)) & 1).bool()
+    assert torch.equal(bits, act > 0)
+    # gradient slice: conv over another prefix, times LeakyReLU' of the slice just written -- mask form vs activation form
+    y_m = torch.zeros(B, H, W, cout, device="cuda", dtype=db.dtype)
+    y_z = torch.zeros_like(y_m)
+    ops.conv_igemm(db, wp, y_m, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), x_plane=pl, shape=(B, H, W), sign_in=sign)
+    ops.conv_igemm(db, wp, y_z, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), mz=db, mz_coff=cin, x_plane=pl, mz_plane=pl, shape=(B, H, W))
+    assert torch.equal(y_m, y_z)
+    # refused: 64 output channels, interleaved input
+    y64 = torch.zeros(B, H, W, 64, device="cuda", dtype=db.dtype)
+    with pytest.raises(RuntimeError):
+        ops.conv_igemm(db, ops.pack_conv2d_fwd(torch.randn(64, cin, 3, 3).cuda(), dt), y64, kh=3, kw=3, Cin=cin, Cout=64, pad=(1, 1),
+                       x_plane=pl, shape=(B, H, W), sign_in=sign)
+    xn = _nhwc(ops, buf, Cc, dt)
+    with pytest.raises(RuntimeError):
+        ops.conv_igemm(xn, wp, y_m, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), sign_in=sign)
+
+
 @pytest.mark.parametrize("blocked", [False, True])
 @pytest.mark.parametrize("hw", [(8, 64), (16, 32), (12, 96)])
 def test_wgrad_dense_production_tiles(ops, blocked, hw):
