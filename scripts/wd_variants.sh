@@ -11,11 +11,14 @@ for v in "$@"; do
   rm -rf $OUT/prof_wdv
   MB_BLOCKED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_wdv -- python $ROOT/scripts/microbench_wgrad_dense.py > $OUT/prof_wdv.log 2>&1 || exit 1
   python - "$v" >> $OUT/wd_variants.txt <<PY
-import csv, glob, sys
-f = glob.glob("$OUT/prof_wdv/**/*kernel_stats.csv", recursive=True)[0]
+import csv, glob, sys, statistics, collections
+f = glob.glob("$OUT/prof_wdv/**/*kernel_trace.csv", recursive=True)[0]
+d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "wgrad_dense_fast" in r["Name"]:
-        print(f"{sys.argv[1]:10s} {r['Name'][:50]:50s} avg {float(r['AverageNs'])/1e3:8.1f} us")
+    if "wgrad_dense_fast" in r["Kernel_Name"]:
+        d[r["Kernel_Name"][:50]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in d.items():
+    print(f"{sys.argv[1]:10s} {k:50s} median {statistics.median(v):8.1f} us  min {min(v):8.1f}  n={len(v)}")
 PY
 done
 rm -rf $OUT/prof_wdv

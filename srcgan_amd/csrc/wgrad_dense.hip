@@ -198,6 +198,9 @@ __device__ __forceinline__ void wd_dma16(const void* base, int voff, int soff, w
 // 283 us with the DMAs issued but out of range -- the issue itself is free, the loss is the memory path pushing back on the
 // issuing (MFMA) waves; a step is 4864 matrix-pipe cycles + the per-wave stall time, because the older wave of each SIMD
 // pair takes the pipe first and the younger one finishes alone (trace: waves 4-7 reach the barrier ~1.2 us after 0-3).
+// Letting the younger wave lead for the first K groups (SG_WD_PRIO_K, s_setprio) evens the arrivals but not the step time.
+// Back-to-back launches of this kernel are power-limited: the first launch of a run takes 357 us, the sustained median is
+// 464 us at ~1.75-1.9 GHz; in the training step (mixed with HBM-bound convolutions) it runs at the 360 us end.
 #ifndef SG_WD_EXP
 #define SG_WD_EXP 0
 #endif
@@ -340,17 +343,28 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
             const char* bb = my_x + (i2 * IWT + xh * 16 + 8 * h + qq + kx) * PB + choff;
             fb[G % (PD + 1)] = tr_frag2(bb, bb + 4 * PB);
         };
+        // Gradient fragments are read lazily: row py is first used by group 6 * py, so only row 0 is read in front of the
+        // loop (with the first PD input fragments) and row py follows FA_LEAD groups ahead of its first use -- the matrix
+        // pipe starts after 4 LDS reads per wave instead of 20 (all 8 waves leave the barrier together and queue on the LDS
+        // port).
+        auto read_a = [&](int py, int xh) {
+            const char* ab = my_d + (py * TW + xh * 16 + 8 * h + qq) * PB + choff;
+            fa[py][xh] = tr_frag2(ab, ab + 4 * PB);
+        };
+        read_a(0, 0); read_b(0); read_a(0, 1);
 #pragma unroll
-        for (int py = 0; py < TH; ++py)
-#pragma unroll
-            for (int xh = 0; xh < 2; ++xh) {
-                const char* ab = my_d + (py * TW + xh * 16 + 8 * h + qq) * PB + choff;
-                fa[py][xh] = tr_frag2(ab, ab + 4 * PB);
-            }
-#pragma unroll
-        for (int G = 0; G < PD; ++G) read_b(G);
+        for (int G = 1; G < PD; ++G) read_b(G);
+        constexpr int FA_LEAD = 4;
+#ifndef SG_WD_PRIO_K
+#define SG_WD_PRIO_K 0
+#endif
 #pragma unroll
         for (int G = 0; G < NGRP; ++G) {
+            if (SG_WD_PRIO_K > 0 && wave >= NW / 2) {       // the younger wave of each SIMD pair leads for the first K groups
+                if (G == 0) __builtin_amdgcn_s_setprio(1);
+                if (G == SG_WD_PRIO_K) __builtin_amdgcn_s_setprio(0);
+            }
+            if ((G + FA_LEAD) % 6 < 2 && (G + FA_LEAD) / 6 >= 1 && (G + FA_LEAD) / 6 < TH) read_a((G + FA_LEAD) / 6, (G + FA_LEAD) % 6);
             if (G + PD < NGRP && !(SG_WD_EXP & 4)) read_b(G + PD);
             if (more && !(SG_WD_EXP & 1)) {              // next tile's pieces ride in the shadow of this tile's MFMAs
 #pragma unroll
@@ -358,6 +372,10 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
                     if (PPK * G + j < IPW) piece(PPK * G + j, stage ^ 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef SG_TRACE
+            if (G % 5 == 0 && p.trace && blockIdx.x == 1 && blockIdx.y == 3 && lane == 0 && t - t_begin == 10)
+                p.trace[192 + wave * 8 + G / 5] = __builtin_amdgcn_s_memrealtime();
+#endif
             const int i2 = G / 6, kx = (G % 6) / 2, xh = G % 2;
 #pragma unroll
             for (int py = 0; py < TH; ++py) {
@@ -366,10 +384,11 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
                 if (!(SG_WD_EXP & 2)) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx], 0, 0, 0);
                 else asm volatile("" :: "v"(fa[py][xh]), "v"(fb[G % (PD + 1)]));
             }
-            // bias pseudo-tap: one MFMA per gradient fragment, placed in the single-MFMA groups of the first/last input row
-            if (do_bias && kx == 0 && (i2 == 0 || i2 == IHT - 1))
+            // bias pseudo-tap: one MFMA per gradient fragment, placed in the light groups of the first/last input rows
+            // (row 0 in input row 0 -- the only gradient row read by then --, the rest in the last two input rows)
+            if (do_bias && kx == 0 && (i2 == 0 || i2 >= IHT - 2))
 #pragma unroll
-                for (int py = (i2 == 0 ? 0 : TH / 2); py < (i2 == 0 ? TH / 2 : TH); ++py)
+                for (int py = (i2 == 0 ? 0 : i2 == IHT - 2 ? 1 : TH / 2); py < (i2 == 0 ? 1 : i2 == IHT - 2 ? TH / 2 : TH); ++py)
                     acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], ones, acc[NTAP], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -469,8 +488,8 @@ static int launch_wd(WdP p, hipStream_t st) {
                                   px * (rows + p.C) * sizeof(T), st);
 #ifdef SG_TRACE
     static unsigned long long* trace = nullptr;
-    if (!trace) SG_HIP(hipMalloc(&trace, 48 * 4 * 8));
-    SG_HIP(hipMemsetAsync(trace, 0, 48 * 4 * 8, st));
+    if (!trace) SG_HIP(hipMalloc(&trace, 64 * 4 * 8));
+    SG_HIP(hipMemsetAsync(trace, 0, 64 * 4 * 8, st));
     p.trace = trace;
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ncit, (unsigned)p.nsplit), dim3(MT * NT * 64), SMEM, st, p);
@@ -479,13 +498,19 @@ static int launch_wd(WdP p, hipStream_t st) {
         static int dumps = 0;
         if (getenv("SRCGAN_TRACE") && dumps < 2 && fast) {
             ++dumps;
-            unsigned long long h[48 * 4];
+            unsigned long long h[64 * 4];
             SG_HIP(hipStreamSynchronize(st));
             SG_HIP(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[trace] %s (10 ns ticks: arrive at barrier, own DMA landed, barrier exit)\n", cls);
             for (int k = 0; k < 4; ++k) {
                 fprintf(stderr, "[trace] step %d arrivals by wave (rel. wave 0):", 8 + k);
                 for (int w = 0; w < 8; ++w) fprintf(stderr, " %5lld", (long long)(h[160 + k * 8 + w] - h[160 + k * 8]));
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "[trace] step 10: time of groups 0,5,..,35 by wave (rel. wave 0 group 0)\n");
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "[trace]   wave %d:", w);
+                for (int g = 0; g < 8; ++g) fprintf(stderr, " %5lld", (long long)(h[192 + w * 8 + g] - h[192]));
                 fprintf(stderr, "\n");
             }
             for (int k = 0; k < 40 && h[k * 4]; ++k)
