@@ -329,6 +329,16 @@ int srcgan_metric_scratch_floats(int B, int C, int H, int W);
 int srcgan_metric_ae(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
 int srcgan_metric_ssim(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
 
+/* Input pipeline colour conversions on device (dataset.py:114-159 behind G2RGB / G2LAB.__getitem__ :179-199,:234-254; the
+ * reference calls skimage.color per sample on the host).  rgb: [B,H*W,3] interleaved 8-bit; dst: f32 planes [B,C,H*W].
+ *   mode 0: gray = rgb2gray(rgb)                               C = 1   (_arr2gray)
+ *   mode 1: rgb / 255                                          C = 3   (_arr2rgb)
+ *   mode 2: (L/100, (a+128)/255, (b+128)/255) of rgb2lab(rgb)  C = 3   (_arr2lab)
+ *   mode 3: ((a+128)/255, (b+128)/255)                         C = 2   (_arr2ab)
+ * srcgan_lab_planes_to_u8rgb is the inverse used for visualisation (_lab2img, dataset.py:92-104; truncating store). */
+int srcgan_u8rgb_to_planes(const unsigned char* rgb, float* dst, int B, long hw, int mode, void* stream);
+int srcgan_lab_planes_to_u8rgb(const float* lab, unsigned char* rgb, int B, long hw, void* stream);
+
 /* Fused multi-tensor Adam (torch.optim.Adam.step() of trainCas.py:38-41,143-150 / train.py:191-192,331-340; torch's
  * single-tensor arithmetic, default flags: no weight decay, no amsgrad).  tensors_dev: device array of records
  * {float* p; const float* g; float* m; float* v;} (32 bytes); chunks_dev: device array of nchunks records

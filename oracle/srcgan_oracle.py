@@ -33,6 +33,7 @@ __all__ = [
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
     "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "edsr_forward", "srdn_forward", "metric_ae", "metric_ssim",
+    "arr2gray", "arr2rgb", "arr2lab", "arr2ab", "lab2img",
 ]
 
 
@@ -600,3 +601,64 @@ def cycle_step(st: CycleState, real_a: Tensor, real_b: Tensor) -> Dict[str, floa
     st.opt_d.step()
     return {"loss_G": float(loss_g), "loss_D_A": float(l_d_a), "loss_D_B": float(l_d_b),
             "loss_cycle": float(l_cyc_a + l_cyc_b), "loss_iden": float(l_iden_a + l_iden_b), "loss_G_GAN": float(l_g_a + l_g_b)}
+
+
+# ---------------------------------------------------------------------------
+# Host input pipeline: colour conversions of dataset.Basic (reference src/dataset.py:92-159)
+# PARITY UNPINNED: the reference delegates to scikit-image 's skimage.color.{rgb2gray, rgb2lab, lab2rgb} (version not pinned by
+# the reference: it ships no requirements file), which is not installed in this image, and the reference holds no fixture
+# for them.  What follows restates scikit-image's published algorithm in float64 numpy (as the reference's ndarray code
+# runs); tests/test_oracle_golden.py anchors it on CIE known answers (white, black, the sRGB primaries) only.
+import numpy as _np
+
+_XYZ_FROM_RGB = _np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+_WHITE_D65_2 = _np.array([0.95047, 1.0, 1.08883])
+
+
+def _rgb2lab_f64(arr_u8):
+    a = _np.asarray(arr_u8).astype(_np.float64) / 255.0                       # img_as_float of an 8-bit image
+    lin = _np.where(a > 0.04045, ((a + 0.055) / 1.055) ** 2.4, a / 12.92)     # rgb2xyz
+    xyz = lin @ _XYZ_FROM_RGB.T / _WHITE_D65_2                                # xyz2lab, illuminant D65, observer 2
+    f = _np.where(xyz > 0.008856, _np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    L = 116.0 * f[..., 1] - 16.0
+    return _np.stack([L, 500.0 * (f[..., 0] - f[..., 1]), 200.0 * (f[..., 1] - f[..., 2])], axis=-1)
+
+
+def arr2gray(arr_u8) -> Tensor:
+    """Basic._arr2gray, dataset.py:114-123: rgb2gray(arr) [H,W,3] uint8 -> [1,H,W] float32."""
+    g = (_np.asarray(arr_u8).astype(_np.float64) / 255.0) @ _np.array([0.2125, 0.7154, 0.0721])
+    return torch.from_numpy(g[None]).float()
+
+
+def arr2rgb(arr_u8) -> Tensor:
+    """Basic._arr2rgb, dataset.py:125-134."""
+    return torch.from_numpy((_np.asarray(arr_u8) / (2 ** 8 - 1)).transpose((2, 0, 1))).float()
+
+
+def arr2lab(arr_u8) -> Tensor:
+    """Basic._arr2lab, dataset.py:148-159."""
+    lab = _rgb2lab_f64(arr_u8)
+    lab[:, :, :1] = lab[:, :, :1] / 100
+    lab[:, :, 1:] = (lab[:, :, 1:] + 128) / 255
+    return torch.from_numpy(lab.transpose((2, 0, 1))).float()
+
+
+def arr2ab(arr_u8) -> Tensor:
+    """Basic._arr2ab, dataset.py:136-146."""
+    ab = (_rgb2lab_f64(arr_u8)[:, :, 1:] + 128) / 255
+    return torch.from_numpy(ab.transpose((2, 0, 1))).float()
+
+
+def lab2img(lab_hw3) -> "_np.ndarray":
+    """Basic._lab2img without the whitespace frame, dataset.py:92-104: normalised LAB [H,W,3] -> uint8 RGB [H,W,3]."""
+    lab = _np.array(lab_hw3, dtype=_np.float64)
+    lab[:, :, :1] = lab[:, :, :1] * 100
+    lab[:, :, 1:] = lab[:, :, 1:] * 255 - 128
+    fy = (lab[..., 0] + 16.0) / 116.0                                         # lab2xyz
+    fx = lab[..., 1] / 500.0 + fy
+    fz = _np.maximum(fy - lab[..., 2] / 200.0, 0.0)
+    f = _np.stack([fx, fy, fz], axis=-1)
+    xyz = _np.where(f > 0.2068966, f ** 3, (f - 16.0 / 116.0) / 7.787) * _WHITE_D65_2
+    rgb = xyz @ _np.linalg.inv(_XYZ_FROM_RGB).T                               # xyz2rgb
+    rgb = _np.where(rgb > 0.0031308, 1.055 * _np.power(_np.maximum(rgb, 0.0), 1 / 2.4) - 0.055, rgb * 12.92)
+    return (_np.clip(rgb, 0, 1) * 255).astype("uint8")

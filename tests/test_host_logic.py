@@ -175,3 +175,41 @@ def test_resdeconv_holder():
         srcgan_amd.ResDeconv(1, 3, layers=(3, 4, 6, 3))
     from srcgan_amd import train as T
     assert T.CasParams().CModel == "ResDeconv" and T.MODEL_REGISTRY["ResDeconv"] is srcgan_amd.ResDeconv
+
+
+def test_checkpoint_names_round_trip(tmp_path):
+    """trainCas.py:221-225 writes '<Model>_A2C_x<up>_<epoch:04d>.pth' / '<CModel>_C2B_...'; testCas.py:41-56 splits the basename on
+    '_' to rebuild both networks.  Names, parsing, and a save -> load round trip of two (tiny) networks with reference keys."""
+    from srcgan_amd import data as D
+    assert D.checkpoint_name("RDDBNet", "A2C", 4, 25) == "RDDBNet_A2C_x4_0025.pth"
+    assert D.checkpoint_name("ResDeconv", "C2B", 2, 300) == "ResDeconv_C2B_x2_0300.pth"
+    assert D.parse_checkpoint_name("./checkpoints/ESPCN_A2C_x2_0050.pth") == ("ESPCN", "A2C", 2, 50)
+    with pytest.raises(ValueError):
+        D.parse_checkpoint_name("weights.pth")
+    with pytest.raises(ValueError):
+        D.checkpoint_name("RDDBNet", "G", 2, 1)
+    reg = {"RDDBNetTiny": lambda i, o, up: srcgan_amd.RDDBNet(i, o, up, nf=16, nb=1, gc=8),
+           "ColourTiny": lambda i, o: srcgan_amd.RDDBNet(i, o, 1, nf=16, nb=1, gc=8)}
+
+    class _M:
+        pass
+    m, opt = _M(), _M()
+    torch.manual_seed(3)
+    m.netG_A2C, m.netG_C2B = reg["RDDBNetTiny"](1, 1, 2), reg["ColourTiny"](1, 3)
+    opt.SRModel, opt.CModel, opt.up = "RDDBNetTiny", "ColourTiny", 2
+    pa, pb = D.save_checkpoints(m, opt, 25, root=str(tmp_path))
+    assert pa.endswith("RDDBNetTiny_A2C_x2_0025.pth") and pb.endswith("ColourTiny_C2B_x2_0025.pth")
+    na, nb = D.load_cascade(pa, pb, device="cpu", registry=reg)
+    assert not na.training and not nb.training
+    for a, b in ((na, m.netG_A2C), (nb, m.netG_C2B)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    with pytest.raises(KeyError):
+        D.load_cascade(pa.replace("RDDBNetTiny", "Nope"), pb, device="cpu", registry=reg)
+
+
+def test_input_pipeline_needs_the_device():
+    """The colour conversions are product code: no CPU fallback, host tensors are refused."""
+    from srcgan_amd import data as D
+    with pytest.raises(RuntimeError):
+        D.arr2lab(torch.zeros(4, 4, 3, dtype=torch.uint8))

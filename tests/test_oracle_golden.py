@@ -284,3 +284,25 @@ def test_srdn(tag):
     assert list(net.state_dict().keys()) == list(ref.keys())
     for k, v in ref.items():
         assert torch.equal(net.state_dict()[k], v), k
+
+
+def test_colour_restatement_known_answers():
+    """dataset.py:114-159 colour conversions (scikit-image, absent here: PARITY UNPINNED).  The float64 restatement is anchored
+    on CIE L*a*b* (D65, 2 degree) known answers for white, black, mid-grey and the sRGB primaries, the luma weights, and the
+    8-bit round trip of `_lab2img` (truncating store: within one code value)."""
+    import numpy as np
+    from oracle import srcgan_oracle as O
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]]], dtype=np.uint8)
+    lab = O._rgb2lab_f64(px)[0]
+    known = np.array([[100.0, 0.0, 0.0], [0.0, 0.0, 0.0], [53.24, 80.09, 67.20], [87.73, -86.18, 83.18], [32.30, 79.19, -107.86], [53.585, 0.0, 0.0]])
+    assert np.abs(lab - known).max() < 0.02
+    g = O.arr2gray(px)[0, 0].numpy()
+    assert np.allclose(g, [1.0, 0.0, 0.2125, 0.7154, 0.0721, 128 / 255], atol=1e-6)
+    n = O.arr2lab(px)
+    assert n.shape == (3, 1, 6) and float(n.min()) >= 0.0 and float(n.max()) <= 1.0
+    assert torch.equal(O.arr2ab(px), n[1:])
+    assert torch.allclose(O.arr2rgb(px)[:, 0, 2], torch.tensor([1.0, 0.0, 0.0]))
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)
+    back = O.lab2img(O.arr2lab(im).numpy().transpose(1, 2, 0))
+    assert np.abs(back.astype(int) - im.astype(int)).max() <= 1
