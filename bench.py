@@ -142,7 +142,8 @@ def main():
 
     torch.manual_seed(0)                         # identical init on every rank, then broadcast anyway
     model = PairedSRGAN(3, 3, args.up, nf=64, nb=args.nb, gc=32, ndf=64, n_layers=3, dtype=args.dtype, device=dev)
-    if world > 1:
+    use_dist = world > 1 or dist.is_initialized()          # one rank + SRCGAN_FORCE_DIST=1 rehearses the RCCL path
+    if use_dist:
         sdist.broadcast_module(model.netG)
         sdist.broadcast_module(model.netD)
         model.grad_sync = sdist.GradSync()
@@ -152,7 +153,7 @@ def main():
     y = torch.rand(B, 3, H, H, generator=g).to(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +165,7 @@ def main():
         model.optimize_parameters(x, y)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -213,7 +214,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -20,13 +20,18 @@ import torch.distributed as dist
 __all__ = ["init_from_env", "broadcast_module", "GradSync", "shard_range"]
 
 
+# SRCGAN_FORCE_DIST=1: create the process group and run the collectives even with one rank (rehearses the RCCL path --
+# rendezvous, broadcast, bucketed all-reduce on the side stream -- on a one-GPU box; tests/test_gpu_dist.py)
+_FORCE = os.environ.get("SRCGAN_FORCE_DIST") == "1"
+
+
 def init_from_env(backend: Optional[str] = None):
     """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract).
     Returns (rank, local_rank, world).  world == 1 -> no process group is created."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -48,7 +53,7 @@ def shard_range(n_units: int, rank: int, world: int):
 @torch.no_grad()
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     """Make every replica identical to rank `src` (parameters and buffers), one flat message per dtype."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return
     tensors = [t for t in list(module.parameters()) + list(module.buffers())]
     by_dtype = {}
@@ -74,7 +79,8 @@ class GradSync:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._side = torch.cuda.Stream() if torch.cuda.is_available() and self.world > 1 else None
+        self._active = self.world > 1 or (_FORCE and dist.is_initialized())
+        self._side = torch.cuda.Stream() if torch.cuda.is_available() and self._active else None
 
     def _buckets(self, grads: List[torch.Tensor]) -> List[List[torch.Tensor]]:
         out, cur, size = [], [], 0
@@ -91,7 +97,7 @@ class GradSync:
 
     @torch.no_grad()
     def allreduce(self, params: Iterable[torch.nn.Parameter]) -> None:
-        if self.world == 1:
+        if not self._active:
             return
         grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
         if not grads:
@@ -107,17 +113,17 @@ class GradSync:
             ctx = contextlib.nullcontext()
         pending = []
         with ctx:
+            # per bucket: one flatten, one collective, one scale of the flat buffer and ONE multi-tensor copy back (a copy_ and
+            # a mul_ per tensor were ~1400 launches = 5.8 ms of a 148 ms step for the 700 generator tensors)
             for bucket in self._buckets(grads):
                 flat = torch.cat([g.reshape(-1) for g in bucket])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 pending.append((work, flat, bucket))
             for work, flat, bucket in pending:
                 work.wait()
-                off = 0
-                for g in bucket:
-                    n = g.numel()
-                    g.copy_(flat[off:off + n].view_as(g)).mul_(inv)
-                    off += n
+                flat.mul_(inv)
+                views = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)]
+                torch._foreach_copy_(bucket, views)
         if cuda:
             main.wait_stream(self._side)
             for _, flat, _ in pending:

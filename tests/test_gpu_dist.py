@@ -1,0 +1,69 @@
+"""GPU: the RCCL code path with ONE rank (SRCGAN_FORCE_DIST=1): rendezvous on 127.0.0.1, nccl process group bound to the device,
+parameter / buffer broadcast, bucketed asynchronous all-reduce on the side stream, barrier + MAX all-reduce of the bench timing.
+The multi-rank arithmetic is covered on CPU (tests/test_dist_gloo.py, gloo, world_size 2); N > 1 GPUs only exist on the driver's
+node.  Runs in a child process (a process group must not leak into the test runner)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _env(port):
+    env = dict(os.environ)
+    env.update(SRCGAN_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_bench_one_rank_through_rccl():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--nb", "1", "--lr-size", "64", "--no-cpu-baseline", "--no-kernel-profile"],
+                         env=_env(29631), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_grad_sync_one_rank_keeps_the_step_identical():
+    """With one rank the averaged gradient is the gradient: a step through broadcast + GradSync equals a plain step bit for bit."""
+    code = r'''
+import torch, sys
+sys.path.insert(0, %r)
+from srcgan_amd import dist as sdist
+from srcgan_amd.train import PairedSRGAN
+rank, local, world = sdist.init_from_env()
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+def run(sync):
+    torch.manual_seed(0)
+    m = PairedSRGAN(3, 3, 2, nf=16, nb=1, gc=8, ndf=16, n_layers=3, dtype="fp32", device="cuda")
+    if sync:
+        sdist.broadcast_module(m.netG); sdist.broadcast_module(m.netD)
+        m.grad_sync = sdist.GradSync(bucket_mb=0.05)          # several buckets
+        assert m.grad_sync._active
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.rand(2, 3, 32, 32, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda()
+    for _ in range(2):
+        m.optimize_parameters(x, y)
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in list(m.netG.parameters()) + list(m.netD.parameters())], float(m.loss_G), float(m.loss_D)
+a, b = run(False), run(True)
+assert a[1] == b[1] and a[2] == b[2], (a[1:], b[1:])
+assert all(torch.equal(p, q) for p, q in zip(a[0], b[0]))
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=_env(29632), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
