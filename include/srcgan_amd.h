@@ -329,6 +329,14 @@ int srcgan_metric_scratch_floats(int B, int C, int H, int W);
 int srcgan_metric_ae(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
 int srcgan_metric_ssim(const float* pred, const float* truth, int B, int C, int H, int W, float* out, float* scratch, void* stream);
 
+/* Space-to-depth forms of an image-channel tensor for a 4x4 stride-2 pad-1 first layer (NLayerDiscriminator, model/model.py:612):
+ * block (j,i) of the (H/2+1) x (W/2+1) grid = the 2x2 pixels (2j-1+dy, 2i-1+dx) as a 32-channel record [dy][dx][8], zero
+ * outside the image / past C; the layer becomes a 2x2 stride-1 convolution with K = 4 x 32 and no padded K.
+ * srcgan_s2d_wgrad_unfold maps the gradient of the folded weight [Cout][32][2][2] to the canonical [Cout][Cin][4][4]. */
+int srcgan_nchw_f32_to_s2d(const float* src, void* dst, int B, int C, int H, int W, int dtype, void* stream);
+int srcgan_s2d_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int dtype, void* stream);
+int srcgan_s2d_wgrad_unfold(const float* gfold, float* grad, int Cout, int Cin, int accumulate, void* stream);
+
 /* Input pipeline colour conversions on device (dataset.py:114-159 behind G2RGB / G2LAB.__getitem__ :179-199,:234-254; the
  * reference calls skimage.color per sample on the host).  rgb: [B,H*W,3] interleaved 8-bit; dst: f32 planes [B,C,H*W].
  *   mode 0: gray = rgb2gray(rgb)                               C = 1   (_arr2gray)

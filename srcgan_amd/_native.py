@@ -152,6 +152,9 @@ SIGNATURES = {
     "srcgan_metric_scratch_floats": (_I, [_I, _I, _I, _I]),
     "srcgan_metric_ae": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "srcgan_metric_ssim": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "srcgan_nchw_f32_to_s2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "srcgan_s2d_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "srcgan_s2d_wgrad_unfold": (_I, [_P, _P, _I, _I, _I, _P]),
     "srcgan_u8rgb_to_planes": (_I, [_P, _P, _I, _L, _I, _P]),
     "srcgan_lab_planes_to_u8rgb": (_I, [_P, _P, _I, _L, _P]),
     "srcgan_adam_step": (_I, [_P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _L, _P]),

@@ -335,6 +335,7 @@ static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st
     if (kh == KH_ && kw == KW_ && s == S_) return launch_wgrad<T, KH_, KW_, S_, MT, TH_, NCW_, BIASW_>(p, st);
     SG_CASE(3, 3, 1, 8, 3, true)
     SG_CASE(2, 2, 2, 4, 4, false)
+    SG_CASE(2, 2, 1, 8, 4, false)       // first discriminator layer in its space-to-depth form
     SG_CASE(4, 4, 2, 4, 4, false)
     SG_CASE(4, 4, 1, 8, 4, false)
     SG_CASE(3, 3, 2, 4, 3, true)

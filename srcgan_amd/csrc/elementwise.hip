@@ -162,6 +162,95 @@ __global__ __launch_bounds__(256) void nhwc8_to_nchw_k(const __bf16* __restrict_
     }
 }
 
+// Space-to-depth forms of an image-channel tensor, for a 4x4 stride-2 pad-1 first layer (model/model.py:612): block (j, i)
+// of the (H/2+1) x (W/2+1) grid holds the 2x2 pixels (2j-1+dy, 2i-1+dx) as a 32-channel record [dy][dx][8] (zero outside
+// the image and past C), so the layer is a 2x2 stride-1 convolution over K = 4 x 32 values with no padded K: the 8-channel
+// NHWC form carries 24 zero channels per 64-byte K chunk through the matrix pipe.  A thread moves one block.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_s2d8_k(const float* __restrict__ src, T* __restrict__ dst, int C, int H, int W, long total) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int BH = H / 2 + 1, BW = W / 2 + 1;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const int i = (int)(q % BW); const long t = q / BW; const int j = (int)(t % BH); const long b = t / BH;
+        T rec[32];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int y = 2 * j - 1 + (s >> 1), x = 2 * i - 1 + (s & 1);
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                rec[s * 8 + c] = from_f<T>((in && c < C) ? src[(((size_t)b * C + c) * H + y) * W + x] : 0.f);
+        }
+        vecT* o = (vecT*)(dst + (size_t)q * 32);
+#pragma unroll
+        for (int v = 0; v < 32 / EPP; ++v) {
+            vecT t2;
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) t2[e] = rec[v * EPP + e];
+            o[v] = t2;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void s2d8_to_nchw_k(const T* __restrict__ src, float* __restrict__ dst, int C, int H, int W, long total) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    const int BH = H / 2 + 1, BW = W / 2 + 1;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const int i = (int)(q % BW); const long t = q / BW; const int j = (int)(t % BH); const long b = t / BH;
+        const vecT* in = (const vecT*)(src + (size_t)q * 32);
+        T rec[32];
+#pragma unroll
+        for (int v = 0; v < 32 / EPP; ++v) {
+            const vecT t2 = in[v];
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) rec[v * EPP + e] = t2[e];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int y = 2 * j - 1 + (s >> 1), x = 2 * i - 1 + (s & 1);
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) dst[(((size_t)b * C + c) * H + y) * W + x] = to_f(rec[s * 8 + c]);
+        }
+    }
+}
+
+// gradient of the folded first-layer weight [Cout][32 = (dy,dx,c8)][2][2] -> canonical [Cout][Cin][4][4]
+__global__ __launch_bounds__(256) void s2d_wgrad_unfold_k(const float* __restrict__ gf, float* __restrict__ g, int Cout, int Cin, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Cout * Cin * 16) return;
+    const int kx = e & 3, ky = (e >> 2) & 3, c = (e >> 4) % Cin, co = (e >> 4) / Cin;
+    const float v = gf[(((size_t)co * 32 + ((ky & 1) * 2 + (kx & 1)) * 8 + c) * 2 + (ky >> 1)) * 2 + (kx >> 1)];
+    g[e] = accumulate ? g[e] + v : v;
+}
+
+extern "C" int srcgan_nchw_f32_to_s2d(const float* src, void* dst, int B, int C, int H, int W, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && C <= 8 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "srcgan_nchw_f32_to_s2d: needs 1..8 channels and even H, W");
+    const long total = (long)B * (H / 2 + 1) * (W / 2 + 1);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_s2d8_k<T>, dim3(ew_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, C, H, W, total));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srcgan_s2d_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int dtype, void* stream) {
+    SG_REQUIRE(src && dst && B > 0 && C > 0 && C <= 8 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "srcgan_s2d_to_nchw_f32: needs 1..8 channels and even H, W");
+    const long total = (long)B * (H / 2 + 1) * (W / 2 + 1);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(s2d8_to_nchw_k<T>, dim3(ew_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, H, W, total));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srcgan_s2d_wgrad_unfold(const float* gfold, float* grad, int Cout, int Cin, int accumulate, void* stream) {
+    SG_REQUIRE(gfold && grad && Cout > 0 && Cin > 0 && Cin <= 8, "srcgan_s2d_wgrad_unfold: bad arguments");
+    hipLaunchKernelGGL(s2d_wgrad_unfold_k, dim3(cdiv(Cout * Cin * 16, 256)), dim3(256), 0, (hipStream_t)stream, gfold, grad, Cout, Cin, accumulate);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cs, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "srcgan_nchw_f32_to_nhwc: bad arguments");
     const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);

@@ -658,6 +658,7 @@ struct DPlan {
     size_t wf[8], wd[8][4];
     int pw[8], pb[8], pg[8], pbeta[8];   // parameter indices (-1 if absent)
     int bn_idx[8];                       // index among BN layers (-1 if none)
+    int s2d;                             // first layer in space-to-depth form (even H, W): 2x2 s1 over 32-channel blocks, K not padded
 };
 
 static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
@@ -682,8 +683,10 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     }
     P.in_cs = img_cs(c->in_ch); P.out_cs = 8;
     const size_t e = P.esz, B = c->B;
+    static const bool no_s2d = getenv("SRCGAN_NO_S2D") != nullptr;
+    P.s2d = !no_s2d && c->H % 2 == 0 && c->W % 2 == 0;
     Bump b;
-    P.xin = b.take(B * c->H * c->W * P.in_cs * e);
+    P.xin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);
     int n = 0, nbn = 0;
     for (int l = 0; l < P.L; ++l) {
         const bool bn = (l >= 1 && l <= P.L - 2), bias = (l == 0 || l == P.L - 1);
@@ -708,8 +711,13 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     Bump wb;
     for (int l = 0; l < P.L; ++l) {
         const int cin_r = l == 0 ? P.in_cs : P.ch[l];
-        P.wf[l] = wb.take(srcgan_packed_weight_bytes(P.ch[l + 1], cin_r, 16, c->dtype));
         const int k_r = l == P.L - 1 ? P.out_cs : P.ch[l + 1];
+        if (l == 0 && P.s2d) {             // folded first layer: forward rows = Cout, k = 32, 4 taps; dgrad rows = 32, k = Cout
+            P.wf[l] = wb.take(srcgan_packed_weight_bytes(P.ch[1], 32, 4, c->dtype));
+            P.wd[l][0] = wb.take(srcgan_packed_weight_bytes(32, k_r, 4, c->dtype));
+            continue;
+        }
+        P.wf[l] = wb.take(srcgan_packed_weight_bytes(P.ch[l + 1], cin_r, 16, c->dtype));
         if (P.st[l] == 1) P.wd[l][0] = wb.take(srcgan_packed_weight_bytes(P.ch[l], k_r, 16, c->dtype));
         else for (int q = 0; q < 4; ++q) P.wd[l][q] = wb.take(srcgan_packed_weight_bytes(P.ch[l], k_r, 4, c->dtype));
     }
@@ -717,7 +725,7 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     return 0;
 }
 
-struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, total; };
+struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, gfold, total; };
 static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q) {
     const size_t e = P.esz, B = c->B;
     Bump b;
@@ -725,10 +733,12 @@ static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q)
     size_t mx = 0;
     for (int l = 0; l < P.L - 1; ++l) { size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mx) mx = s; }
     Q.g[0] = b.take(mx); Q.g[1] = b.take(mx);
-    Q.dxin = b.take(B * c->H * c->W * P.in_cs * e);
+    Q.dxin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);
+    Q.gfold = b.take((size_t)P.ch[1] * 32 * 4 * sizeof(float));
     size_t slab = 0;
     for (int l = 0; l < P.L; ++l) {
-        size_t s = wgrad_slab(c->B, P.hh[l + 1], P.ww[l + 1], P.ch[l + 1], P.ch[l], 4, 4, P.st[l]);
+        size_t s = (l == 0 && P.s2d) ? wgrad_slab(c->B, P.hh[1], P.ww[1], P.ch[1], 32, 2, 2, 1)
+                                     : wgrad_slab(c->B, P.hh[l + 1], P.ww[l + 1], P.ch[l + 1], P.ch[l], 4, 4, P.st[l]);
         if (s > slab) slab = s;
     }
     Q.slab = b.take(slab);
@@ -758,18 +768,28 @@ extern "C" int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* 
     char* w8 = (char*)ws; char* wp = w8 + P.wpk;
     {
         PackList packs(dt, wp);
-        for (int l = 0; l < P.L; ++l)
+        for (int l = 0; l < P.L; ++l) {
+            if (l == 0 && P.s2d) {
+                // W[co][c][2ty+dy][2tx+dx] -> k = (dy,dx,c8), taps (ty,tx): one part per (dy,dx); channels c >= Cin stay zero
+                SG_HIP(hipMemsetAsync(wp + P.wf[0], 0, srcgan_packed_weight_bytes(P.ch[1], 32, 4, dt), (hipStream_t)st));
+                for (int q = 0; q < 4; ++q)
+                    packs.add(params[P.pw[0]], wp + P.wf[0], P.ch[1], P.ch[0], 2, 2, (long)P.ch[0] * 16, 16, 8, 2, (q >> 1) * 4 + (q & 1), q * 8, 32);
+                continue;
+            }
             packs.add(params[P.pw[l]], wp + P.wf[l], P.ch[l + 1], P.ch[l], 4, 4, (long)P.ch[l] * 16, 16, 4, 1, 0);
-        SG_TRY(packs.run("d_fwd", params[0], st));
+        }
+        SG_TRY(packs.run(P.s2d ? "d_fwd_s2d" : "d_fwd", params[0], st));
     }
-    SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
-    TRef cur = tref(w8 + P.xin, P.in_cs);
+    if (P.s2d) SG_TRY(srcgan_nchw_f32_to_s2d(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, dt, st));
+    else SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
+    TRef cur = tref(w8 + P.xin, P.s2d ? 32 : P.in_cs);
     for (int l = 0; l < P.L; ++l) {
         const int cin_r = l == 0 ? P.in_cs : P.ch[l], cout = P.ch[l + 1];
         const int oh = P.hh[l + 1], ow = P.ww[l + 1];
         const long npix = (long)B * oh * ow;
-        Conv cv(dt, 4, 4, P.st[l]);
-        cv.in(cur, B, P.hh[l], P.ww[l], cin_r).w(wp + P.wf[l], P.pb[l] >= 0 ? params[P.pb[l]] : nullptr).pad(1, 1);
+        Conv cv(dt, (l == 0 && P.s2d) ? 2 : 4, (l == 0 && P.s2d) ? 2 : 4, (l == 0 && P.s2d) ? 1 : P.st[l]);
+        if (l == 0 && P.s2d) cv.in(cur, B, c->H / 2 + 1, c->W / 2 + 1, 32).w(wp + P.wf[l], params[P.pb[l]]).pad(0, 0);
+        else cv.in(cur, B, P.hh[l], P.ww[l], cin_r).w(wp + P.wf[l], P.pb[l] >= 0 ? params[P.pb[l]] : nullptr).pad(1, 1);
         if (l == 0) {                       // conv + bias + LeakyReLU (model/model.py:612)
             TRef y = tref(w8 + P.Y[l], cout);
             SG_TRY(cv.out(y, oh, ow, cout).lrelu().run(st));
@@ -818,6 +838,18 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
     for (int l = 0; l < P.L; ++l) {
         if (l == 0 && !dx_nchw) continue;
         const int cin = P.ch[l], cout = P.ch[l + 1];
+        if (l == 0 && P.s2d) {
+            // dX'[j,i,(dy,dx,c)] = sum_{u,v,co} dY[j-1+u, i-1+v, co] * W[co][c][2(1-u)+dy][2(1-v)+dx]: rows (dy,dx,c8), k = co, 2x2 taps.
+            // The rows of one (dy,dx) are a strided slice of the weight: one part per (dy,dx) and per half of k (so that no part
+            // is a whole matrix, which would zero-fill all 32 rows of its view), written at row offset (dy*2+dx)*8.
+            const int kce = 64 / P.esz;
+            SG_HIP(hipMemsetAsync(wp + P.wd[0][0], 0, srcgan_packed_weight_bytes(32, cout, 4, dt), (hipStream_t)st));
+            for (int q = 0; q < 4; ++q)
+                for (int hk = 0; hk < 2; ++hk)
+                    packs.add(params[P.pw[0]], wp + P.wd[0][0] + (size_t)q * 8 * kce * P.esz, cin, cout / 2, 2, 2, 16, (long)cin * 16, -8, -2,
+                              10 + (q >> 1) * 4 + (q & 1) + (long)hk * (cout / 2) * cin * 16, hk * (cout / 2), cout);
+            continue;
+        }
         if (P.st[l] == 1)
             packs.add(params[P.pw[l]], wp + P.wd[l][0], cin, cout, 4, 4, 16, (long)cin * 16, -4, -1, 15);
         else
@@ -827,7 +859,7 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
                 packs.add(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off);
             }
     }
-    SG_TRY(packs.run(dx_nchw ? "d_bwd_dx" : "d_bwd", params[0], st));
+    SG_TRY(packs.run(P.s2d ? (dx_nchw ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (dx_nchw ? "d_bwd_dx" : "d_bwd"), params[0], st));
     // ---- dy -> NHWC (1 channel, padded with zeros to 8)
     const int Lh = P.hh[P.L], Lw = P.ww[P.L];
     TRef dcur = tref(s8 + Q.dO, P.out_cs);
@@ -847,12 +879,24 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
             if (grads[P.pg[l]]) SG_HIP(hipMemcpyAsync(grads[P.pg[l]], sums + cout, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
             SG_TRY(srcgan_bn_bwd_apply(dcur.p, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, dt, st));
         }
-        TRef xin_l = l == 0 ? tref(w8 + P.xin, P.in_cs) : tref(w8 + P.Y[l - 1], cin);
-        if (grads[P.pw[l]])
+        TRef xin_l = l == 0 ? tref(w8 + P.xin, P.s2d ? 32 : P.in_cs) : tref(w8 + P.Y[l - 1], cin);
+        if (grads[P.pw[l]]) {
+            if (l == 0 && P.s2d) {          // gradient of the folded weight, then back to [Cout][Cin][4][4]
+                float* gfold = (float*)(s8 + Q.gfold);
+                SG_TRY(wgrad_call(dt, dcur, oh, ow, cout, xin_l, B, c->H / 2 + 1, c->W / 2 + 1, 32, 2, 2, 1, 0, 0, lay_fwd(32, 2, 2), 1.f, slab, gfold, st));
+                SG_TRY(srcgan_s2d_wgrad_unfold(gfold, grads[P.pw[l]], cout, cin, 0, st));
+            } else
             SG_TRY(wgrad_call(dt, dcur, oh, ow, cout, xin_l, B, ih, iw, cin, 4, 4, P.st[l], 1, 1, lay_fwd(cin, 4, 4), 1.f, slab, grads[P.pw[l]], st));
+        }
         if (P.pb[l] >= 0 && grads[P.pb[l]]) SG_TRY(bias_grad(dt, dcur, npix, cout, 1.f, grads[P.pb[l]], colscr, st));
         if (l == 0 && !dx_nchw) break;
         // dgrad -> gradient of the layer input, times LeakyReLU' of that input (it is some layer's post-activation)
+        if (l == 0 && P.s2d) {              // one 2x2 "full" convolution into the space-to-depth gradient, then back to NCHW f32
+            TRef dst = tref(s8 + Q.dxin, 32);
+            SG_TRY(Conv(dt, 2, 2, 1).in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[0][0]).out(dst, c->H / 2 + 1, c->W / 2 + 1, 32).pad(1, 1).run(st));
+            SG_TRY(srcgan_s2d_to_nchw_f32(dst.p, dx_nchw, B, c->in_ch, c->H, c->W, dt, st));
+            return 0;
+        }
         TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g[l & 1], cin);
         if (l == 0) SG_HIP(hipMemsetAsync(dst.p, 0, (size_t)B * ih * iw * P.in_cs * P.esz, (hipStream_t)st));
         TRef mz = l == 0 ? TNULL : tref(w8 + P.Y[l - 1], cin);

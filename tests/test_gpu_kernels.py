@@ -443,3 +443,37 @@ def test_stem_and_shortcut_convs(ops, dt, k, s, pad, cin, cout, hw):
     gw = torch.zeros(cout, cin, k, k, device="cuda")
     ops.conv_wgrad(_nhwc(ops, dy, ycs, dt), xg, gw, kh=k, kw=k, stride=s, Cout=cout, Cin=cin, pad=(pad, pad), layout=(cin * k * k, k * k, k, 1, 0))
     assert rel_err(gw.cpu(), w.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 12), (1, 1, 34, 6), (2, 8, 16, 16)])
+def test_space_to_depth_forms(ops, dt, shape):
+    """Space-to-depth image forms of the discriminator's first layer (4x4 s2 p1 == 2x2 s1 over 32-channel blocks): layout of
+    srcgan_nchw_f32_to_s2d (block (j,i) = pixels (2j-1+dy, 2i-1+dx), zero outside / past C), its inverse, and the folded-weight
+    gradient map -- all exact (pure data movement; bf16 rounds once)."""
+    import ctypes as C
+    from srcgan_amd import _native as N
+    B, Cc, H, W = shape
+    torch.manual_seed(31)
+    x = (torch.rand(B, Cc, H, W) - 0.5).cuda()
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    BH, BW = H // 2 + 1, W // 2 + 1
+    s2d = torch.full((B, BH, BW, 32), 7.0, dtype=tdt, device="cuda")
+    st = N.stream_ptr(x.device)
+    N.check(N.lib().srcgan_nchw_f32_to_s2d(x.data_ptr(), s2d.data_ptr(), B, Cc, H, W, N.dtype_id(tdt), st), "to_s2d")
+    xp = torch.zeros(B, 8, H + 2, W + 2, device="cuda")
+    xp[:, :Cc, 1:-1, 1:-1] = x.to(tdt).float()
+    ref = xp.view(B, 8, BH, 2, BW, 2).permute(0, 2, 4, 3, 5, 1).reshape(B, BH, BW, 32)          # [dy][dx][c8]
+    assert torch.equal(s2d.float(), ref)
+    back = torch.full((B, Cc, H, W), -3.0, device="cuda")
+    N.check(N.lib().srcgan_s2d_to_nchw_f32(s2d.data_ptr(), back.data_ptr(), B, Cc, H, W, N.dtype_id(tdt), st), "from_s2d")
+    assert torch.equal(back, x.to(tdt).float())
+    # folded weight gradient [Cout][(dy,dx,c8)][ty][tx] -> [Cout][Cin][2ty+dy][2tx+dx]
+    co = 5
+    gf = torch.randn(co, 2, 2, 8, 2, 2, device="cuda")
+    g = torch.zeros(co, Cc, 4, 4, device="cuda")
+    N.check(N.lib().srcgan_s2d_wgrad_unfold(gf.data_ptr(), g.data_ptr(), co, Cc, 0, st), "unfold")
+    refg = gf[:, :, :, :Cc].permute(0, 3, 4, 1, 5, 2).reshape(co, Cc, 4, 4)                       # [co][c][ty][dy][tx][dx]
+    assert torch.equal(g, refg)
+    with pytest.raises(RuntimeError):
+        N.check(N.lib().srcgan_nchw_f32_to_s2d(x.data_ptr(), s2d.data_ptr(), B, Cc, H + 1, W, N.dtype_id(tdt), st), "odd")

@@ -114,16 +114,18 @@ def test_nlayerd_golden_f32(tag):
         assert rel_err(net(x.detach()).cpu(), g["y_eval"]) < F32_TOL
 
 
+@pytest.mark.parametrize("hw", [(96, 128), (97, 128)])
 @pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 8e-2)])
-def test_nlayerd_full_width_vs_oracle(dt, tol):
-    """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch, incl. a frozen pass (dgrad only).
+def test_nlayerd_full_width_vs_oracle(dt, tol, hw):
+    """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch (first layer in its space-to-depth form) and on an odd
+    height (plain 4x4 s2 form), incl. a frozen pass (dgrad only).
     bf16 bound is loose on purpose: with a constant lsgan label the incoming gradient is nearly uniform per channel,
     so BatchNorm backward (g - mean g - xhat * mean(g xhat)) cancels most of a bf16-rounded g (f32 mode: 4e-6)."""
     from srcgan_amd import NLayerDiscriminator, GANLoss
     sd = oracle.nlayer_d_state(3, 64, 3, seed=5)
     net = _load(NLayerDiscriminator(3, 64, 3, dtype=dt), sd)
     torch.manual_seed(1)
-    x = torch.rand(2, 3, 96, 128)
+    x = torch.rand(2, 3, *hw)
     ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     xr = x.clone().requires_grad_(True)
     yr = oracle.nlayer_d_forward(ref_sd, xr, True)
