@@ -293,7 +293,7 @@ extern "C" int srcgan_conv_wgrad_nsplit(int B, int OH, int OW, int Cout, int Cin
     const int th = stride == 2 ? 4 : 8;
     const long ntiles = (long)B * cdiv(OH, th) * cdiv(OW, 32);
     const long pairs = (long)cdiv(Cout, wg_cot(Cout)) * cdiv(Cin, 32);
-    long want = cdivl(1024, pairs);          // ~4 workgroups per CU over the chip
+    long want = cdivl(1024, pairs);          // ~4 workgroups per CU over the chip (1280-4096 measured no better)
     if (want > ntiles) want = ntiles;
     if (want > 256) want = 256;
     if (want < 1) want = 1;
@@ -337,7 +337,9 @@ static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st
     SG_CASE(2, 2, 2, 4, 4, false)
     SG_CASE(2, 2, 1, 8, 4, false)       // first discriminator layer in its space-to-depth form
     SG_CASE(4, 4, 2, 4, 4, false)
-    SG_CASE(4, 4, 1, 8, 4, false)
+    // 4-row tiles: 32 KB of LDS per workgroup -> 4-5 workgroups (16-20 waves) per CU hide the register-staged global loads;
+    // 8-row tiles (57 KB, 2 workgroups per CU) ran the 256->512 layer at 638 TFLOP/s against 840 (scripts/microbench_dwgrad.py)
+    SG_CASE(4, 4, 1, 4, 4, false)
     SG_CASE(3, 3, 2, 4, 3, true)
     SG_CASE(1, 1, 2, 4, 4, false)
     SG_CASE(1, 1, 1, 8, 4, false)
