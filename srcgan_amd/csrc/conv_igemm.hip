@@ -116,35 +116,53 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         }
     };
 
+    // WPK (4x4 and larger kernels): one kernel row of weights in LDS at a time (LDS budget).  The row is prefetched into
+    // registers one row ahead -- while the previous row's MFMAs run -- so its L2 latency is not exposed between two
+    // barriers (it was: 16 MFMAs per wave against a 1-2 us load, matrix pipe 22 % busy on the 4x4 stride-2 layers).
+    u32x4 wv[WPK ? WIT : 1];
+    auto issue_wrow = [&](int c, int ky) {
+        if constexpr (WPK) {
+            const char* ws = wb + ((size_t)c * NTAP + (size_t)ky * KW) * COT * 64;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pc = it * 256 + tid;
+                wv[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
+            }
+        }
+    };
+    auto write_wrow = [&]() {
+        if constexpr (WPK) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pc = it * 256 + tid;
+                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wv[it];
+            }
+        }
+    };
+
     issue_halo(0);
     issue_w(0);
+    issue_wrow(0, 0);
     for (int c = 0; c < p.nchunk; ++c) {
         // registers (chunk c) -> LDS; the previous chunk's readers passed the barrier at the loop bottom
         write_halo(c);
         write_w();
+        write_wrow();                 // kernel row 0 of this chunk
         __syncthreads();
         if (c + 1 < p.nchunk) {       // prefetch the next chunk: in flight while this chunk's MFMAs run
             issue_halo(c + 1);
             issue_w(c + 1);
         }
-        const char* wc = wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
-            if constexpr (WPK) {      // 4x4 kernels: one kernel row of weights at a time (LDS budget)
-                if (ky > 0) __syncthreads();
-                const char* ws = wc + (size_t)ky * KW * COT * 64;
-                u32x4 wv[WIT];
-#pragma unroll
-                for (int it = 0; it < WIT; ++it) {
-                    const int pc = it * 256 + tid;
-                    wv[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
+            if constexpr (WPK) {
+                if (ky > 0) {
+                    __syncthreads();  // the previous row's readers are done
+                    write_wrow();
+                    __syncthreads();
                 }
-#pragma unroll
-                for (int it = 0; it < WIT; ++it) {
-                    const int pc = it * 256 + tid;
-                    if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wv[it];
-                }
-                __syncthreads();
+                if (ky + 1 < KH) issue_wrow(c, ky + 1);
+                else if (c + 1 < p.nchunk) issue_wrow(c + 1, 0);
             }
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {

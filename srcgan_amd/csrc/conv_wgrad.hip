@@ -336,7 +336,7 @@ static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st
     SG_CASE(3, 3, 1, 8, 3, true)
     SG_CASE(2, 2, 2, 4, 4, false)
     SG_CASE(2, 2, 1, 8, 4, false)       // first discriminator layer in its space-to-depth form
-    SG_CASE(4, 4, 2, 4, 4, false)
+    SG_CASE(4, 4, 2, 2, 4, false)       // 2-row tiles: 33 KB of LDS, 4 workgroups per CU (4 rows: 58 KB, 2 per CU; 128->256 @256: 553 -> 407 us)
     // 4-row tiles: 32 KB of LDS per workgroup -> 4-5 workgroups (16-20 waves) per CU hide the register-staged global loads;
     // 8-row tiles (57 KB, 2 workgroups per CU) ran the 256->512 layer at 638 TFLOP/s against 840 (scripts/microbench_dwgrad.py)
     SG_CASE(4, 4, 1, 4, 4, false)
