@@ -69,8 +69,12 @@ class PairedSRGAN:
         self.loss_L1 = self.criterionL1(self.fake, y)
         self.loss_G = self.loss_G_GAN + self.loss_L1 * self.lambda_l1
         self.loss_G.backward()
-        self._sync(self.netG.parameters())
-        self.optimizer_G.step()
+        # Data parallel: the generator's gradient all-reduce runs on the side stream UNDER the discriminator step, which reads
+        # neither the generator's gradients nor its parameters (it sees fake.detach()); optimizer_G.step() therefore moves
+        # behind the discriminator's backward -- same arithmetic, same results as the reference order (train.py:331-340).
+        pending_g = self.grad_sync.begin(self.netG.parameters()) if self.grad_sync is not None else None
+        if self.grad_sync is None:
+            self.optimizer_G.step()
         # ---- discriminator
         set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
@@ -78,6 +82,9 @@ class PairedSRGAN:
         loss_fake = self.criterionGAN(self.netD(self.fake.detach()), False)
         self.loss_D = (loss_real + loss_fake) * 0.5
         self.loss_D.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.end(pending_g)
+            self.optimizer_G.step()
         self._sync(self.netD.parameters())
         self.optimizer_D.step()
 
