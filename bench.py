@@ -173,12 +173,16 @@ def main():
 
     # ---- per-kernel roofline: one extra step with HIP events around every conv launch (launch stream)
     roofline, kernels = None, []
-    if rank == 0 and not args.no_kernel_profile:
-        N.prof_enable(True)
+    # EVERY rank runs the extra step (it contains the gradient collectives: a rank-0-only step would leave rank 0's
+    # all-reduces without partners); only rank 0 brackets its launches with events.
+    if not args.no_kernel_profile:
+        if rank == 0:
+            N.prof_enable(True)
         model.optimize_parameters(x, y)
         torch.cuda.synchronize()
-        N.prof_enable(False)
-        kernels = sorted(N.prof_collect(), key=lambda k: -k["ms"])
+        if rank == 0:
+            N.prof_enable(False)
+            kernels = sorted(N.prof_collect(), key=lambda k: -k["ms"])
         if kernels:
             k = kernels[0]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12

@@ -31,6 +31,11 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks for a one-GPU box (tests/test_gpu_dist.py): several ranks share device SRCGAN_LOCAL_DEVICE and talk
+    # over SRCGAN_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)
+    if os.environ.get("SRCGAN_LOCAL_DEVICE") is not None:
+        local = int(os.environ["SRCGAN_LOCAL_DEVICE"])
+    backend = backend or os.environ.get("SRCGAN_DIST_BACKEND")
     if (world > 1 or _FORCE) and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

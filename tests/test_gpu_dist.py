@@ -67,3 +67,24 @@ print("ok")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], env=_env(29632), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_bench_two_ranks_on_one_device_over_gloo():
+    """bench.py's whole control flow with world_size 2 (torch.distributed.run, 127.0.0.1): broadcast, the generator reduce under
+    the discriminator step, barriers, MAX of the timing, the instrumented extra step on every rank, one JSON line from rank 0.
+    Both ranks share the box's one GPU and talk over gloo (rehearsal hooks in srcgan_amd/dist.py); RCCL itself is covered with
+    one rank above."""
+    env = dict(os.environ)
+    env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SRCGAN_FORCE_DIST"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "2", "--nb", "1", "--lr-size", "64"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
+    assert line["roofline"] is not None and line["cpu_baseline"] is None
