@@ -20,7 +20,15 @@ def _gpu():
         pytest.skip("needs a GPU")
 
 
-def _env(port):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _env(port=None):
+    port = port or _free_port()
     env = dict(os.environ)
     env.update(SRCGAN_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -30,7 +38,7 @@ def _env(port):
 def test_bench_one_rank_through_rccl():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
                           "--nb", "1", "--lr-size", "64", "--no-cpu-baseline", "--no-kernel-profile"],
-                         env=_env(29631), cwd=ROOT, capture_output=True, text=True, timeout=600)
+                         env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
@@ -65,7 +73,7 @@ assert all(torch.equal(p, q) for p, q in zip(a[0], b[0]))
 dist.barrier(); dist.destroy_process_group()
 print("ok")
 ''' % ROOT
-    out = subprocess.run([sys.executable, "-c", code], env=_env(29632), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
 
 
@@ -79,7 +87,7 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SRCGAN_FORCE_DIST"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--batch", "2", "--nb", "1", "--lr-size", "64"],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
