@@ -221,7 +221,7 @@ __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, 
 // holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
 // 2.6 us per chunk against 1.2 us of MFMA), and the weights are 18 of the 57 KiB a stage moves.  Needs ctiles == 1 and
 // nchunk * 18 KiB + two halo stages within 160 KiB (Cin <= 128 in bf16).
-template <typename T, int MT, int NLW, bool WRES, int EM>
+template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG = 2>
 __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
     constexpr int NWV = 8, PT = 2;
@@ -234,9 +234,21 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     // whole rounds of NLW pieces and the surplus pieces carry out-of-range offsets (zero fill, no memory traffic)
     constexpr int HBYTES = HIT * NLW * 1024, WBYTES = WRES ? 0 : WIT * NLW * 1024, SBYTES = HBYTES + WBYTES;
     constexpr int WCH = NTAP * COT * 64;                         // packed weight bytes per K chunk
-    const int wres_bytes = WRES ? p.nchunk * WCH : 0;            // resident weights sit behind the two stages
-    const int bias_off = 2 * SBYTES + wres_bytes;
+    // NSTG stages: the loaders keep NSTG - 1 of them in flight.  With 2 stages a chunk period is one whole landing (DMA issue +
+    // memory latency, 0.9 us with an idle chip, 1.5 us beside the MFMA stream and the epilogue stores), not hidden behind
+    // anything: loads, MFMAs and epilogue of a unit ran back to back (49 us = 29 + 10 + 13 for 64->32 at the bench size).  A
+    // third stage fits beside resident weights for Cin = 64 (3 x 40 + 36 + 4 KiB = 160 KiB) and overlaps two landings.
+    static_assert(NSTG == 2 || NSTG == 3, "stage count");
+    const int wres_bytes = WRES ? p.nchunk * WCH : 0;            // resident weights sit behind the stages
+    const int bias_off = NSTG * SBYTES + wres_bytes;
     constexpr int ERS = COT * 4 + 16;
+    // dense-block convolutions: epilogue straight from the accumulator layout (conv_epilogue_direct32), no scratch, no barrier
+#ifdef SG_NO_DIRECT_EPI
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = MT == 1 && sizeof(T) == 2 && (EM == 0 || EM == 8 || EM == 16);
+#endif
+    const bool direct_ok = p.Cout == 32 && p.os == 1 && p.oa == 0 && p.ob == 0 && p.YH == p.OH && p.YW == p.OW && (p.yplane == 64 ? p.ycoff % 4 == 0 : p.ycoff % 32 == 0);
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,32 +348,46 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
             // all chunks' weights, once: piece j = 1 KiB = 16 packed rows; lane offset is piece-independent (16 | rows per piece)
             const int lo = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
             for (int j = iw; j < p.nchunk * (WCH / 1024); j += NLW)
-                dma_buf16(p.wp, wres_bytes, lo, (lptr_t)(smem + 2 * SBYTES + j * 1024), j * 1024);
+                dma_buf16(p.wp, wres_bytes, lo, (lptr_t)(smem + NSTG * SBYTES + j * 1024), j * 1024);
         }
-        issue(0, 0);
+        // (ac, au): the next chunk to issue, NSTG - 1 chunks ahead of the one the MFMA waves are about to consume; the unit
+        // decode (uct, utx, uty, ub) belongs to it
+        int ac = 0, au = u0, astage = 0;
+        auto issue_next = [&]() __attribute__((always_inline)) {        // false when the workgroup's chunks are exhausted
+            if (au >= u_hi) return false;
+            issue(ac, astage);
+            astage = astage + 1 == NSTG ? 0 : astage + 1;
+            if (++ac == p.nchunk) { ac = 0; au += gw; if (au < u_hi) advance(); }
+            return true;
+        };
+        bool ahead = true;
+#pragma unroll
+        for (int k = 0; k < NSTG - 1; ++k) ahead = issue_next();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the LDS bias copy
-        int stage = 0;
         int trk = 0;
         for (int u = u0; u < u_hi; u += gw) {
-            for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
+            for (int c = 0; c < p.nchunk; ++c) {
 #ifdef SG_TRACE
-                __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): my DMA pieces landed
+                if (NSTG == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HIT) : "memory");
+                else __builtin_amdgcn_s_waitcnt(0x0f70);     // my DMA pieces of this chunk landed
                 const unsigned long long t_land = __builtin_amdgcn_s_memrealtime();
 #endif
-                sg_barrier_dma();                // my pieces of this stage landed (vmcnt 0); MFMA waves left the other stage
+                // my pieces of this chunk's stage landed; MFMA waves left the stage that is issued next.  With 3 stages the
+                // newest stage (HIT pieces per wave, issued last, completing in order) may still be in flight.
+                if (NSTG == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(HIT) : "memory");
+                else sg_barrier_dma();
 #ifdef SG_TRACE
                 const unsigned long long t_bar = __builtin_amdgcn_s_memrealtime();
 #endif
                 if (p.dbg & 2) continue;
-                if (c + 1 < p.nchunk) issue(c + 1, stage ^ 1);
-                else if (u + gw < u_hi) { advance(); issue(0, stage ^ 1); }
+                ahead = issue_next();
 #ifdef SG_TRACE
                 if (p.trace && blockIdx.x == 8 && iw == 0 && lane == 0 && trk < 60) {
                     p.trace[trk * 8 + 0] = t_land; p.trace[trk * 8 + 1] = t_bar; p.trace[trk * 8 + 2] = __builtin_amdgcn_s_memrealtime(); ++trk;
                 }
 #endif
             }
-            if (p.vec16) sg_barrier_raw();       // matches the MFMA waves' pre-epilogue barrier; the next stage keeps flying
+            if (p.vec16 && !(DIRECT && direct_ok)) sg_barrier_raw();       // matches the MFMA waves' pre-epilogue barrier; the next stage keeps flying
         }
         return;
     }
@@ -390,7 +416,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
             const int lp = L0 + (g / 3) * IWT + (g % 3);
             pb[g] = lp * 64 + ((h ^ ((lp >> 2) & 3)) * 16);
         }
-        pa = (WRES ? 2 * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
+        pa = (WRES ? NSTG * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
     }
     int stage = 0;
     int trk = 0;
@@ -406,7 +432,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
             for (int q = 0; q < PT; ++q)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
-        for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
+        for (int c = 0; c < p.nchunk; ++c, stage = (stage + 1 == NSTG ? 0 : stage + 1)) {
 #ifdef SG_TRACE
             const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -459,6 +485,12 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (DIRECT) {
+            if (direct_ok) {
+                if (!(p.dbg & 4)) conv_epilogue_direct32<PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+                continue;
+            }
+        }
         if (p.vec16) {
 #ifdef SG_TRACE
             const unsigned long long t_pre = __builtin_amdgcn_s_memrealtime();
@@ -467,7 +499,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #ifdef SG_TRACE
             const unsigned long long t_eb = __builtin_amdgcn_s_memrealtime();
 #endif
-            char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);
+            char* tsp = smem + (stage == 0 ? NSTG - 1 : stage - 1) * SBYTES + wave * (32 * ERS);      // the stage just consumed: refilled only after the next chunk barrier
             if (!(p.dbg & 4))
                 conv_epilogue_lds_rows<T, MT, PT, EM>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
 #ifdef SG_TRACE
@@ -481,11 +513,12 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     }
 }
 
-template <typename T, int MT, int NLW, bool WRES = false, int EM = 7>
+template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG = 2>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
     constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
-    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM>;
+    static_assert(NSTG == 2 || WRES, "three stages only beside resident weights");
+    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -501,7 +534,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "", EM);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -599,6 +632,13 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
             // epilogue operand set: Cout <= 32 convs are the dense-block forward (none) and its gradient slices (mz)
             const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0) | (p.sgn_in ? 8 : 0) | (p.sgn_out ? 16 : 0);
             SG_REQUIRE(em < 8 || em == 8 || em == 16, "conv3x3: a sign mask cannot be combined with other epilogue operands");
+            static const bool no_s3 = getenv("SRCGAN_NO_S3") != nullptr;
+            if (!no_wres && !no_s3 && p.nchunk == 2) {           // Cin = 64: three 40 KiB stages + 36 KiB of weights + bias = 160 KiB
+                if (em == 0) return launch_ls<T, 1, 8, true, 0, 3>(p, 1, st);
+                if (em == 4) return launch_ls<T, 1, 8, true, 4, 3>(p, 1, st);
+                if (em == 8) return launch_ls<T, 1, 8, true, 8, 3>(p, 1, st);
+                if (em == 16) return launch_ls<T, 1, 8, true, 16, 3>(p, 1, st);
+            }
             if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) {
                 if (em == 0) return launch_ls<T, 1, 8, true, 0>(p, 1, st);
                 if (em == 4) return launch_ls<T, 1, 8, true, 4>(p, 1, st);

@@ -344,6 +344,53 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
     }
 }
 
+// Direct epilogue of the loader-specialised 3x3 kernel for the dense-block convolutions (bf16, 32 output channels, unscaled
+// output, no residual operands: EM = 0, 8 (sign mask read) or 16 (sign mask write)).  No LDS transposition: a lane keeps the
+// accumulator layout -- 4 consecutive channels of pixel r for 4 channel groups -- and stores four 8-byte pieces; the lanes
+// r and r + 32 fill the two halves of each 16 bytes, the four pieces of a 64-byte pixel record leave back to back and merge
+// in L2.  The transposed form cost 1.4 us of a 5.6 us unit (Cin = 64; trace) plus a workgroup barrier in front of it (its
+// scratch is a stage buffer); this one is ~150 VALU instructions per wave and needs no barrier, so a wave goes from its last
+// MFMA straight to its stores.  Bias comes from the LDS copy; the sign mask word of a pixel is read by both of its lanes, and
+// written by the h == 0 lane after a cross-half exchange.
+template <int PT, int EM>
+__device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32x16 (&acc)[1][PT], const char* lds_bias,
+                                                       int b, int oy0, int ox0, int lane) {
+    using T = __bf16;
+    const int r = lane & 31, h = lane >> 5;
+    const int ox = ox0 + r;
+    const bool xok = ox < p.OW;
+    // the 32 channels of the slice lie inside one 64-byte chunk (ycoff % 32 == 0 for blocked tensors; interleaved: linear)
+    const long lch0 = (long)chan_off<T>(p.ycoff + 4 * h, p.yplane);
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int oy = oy0 + q;
+        if (oy >= p.OH) continue;                         // wave-uniform
+        const long pix = ((long)b * p.OH + oy) * p.OW + ox;
+        unsigned sg = 0xffffffffu;
+        if ((EM & 8) && xok) sg = ((const unsigned*)p.sgn_in)[pix];
+        char* yp = (char*)p.y + pix * p.ypix;
+        unsigned mine = 0u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+            const f32x4 bias = *(const f32x4*)(lds_bias + (8 * g + 4 * h) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = (acc[0][q][4 * g + i] + bias[i]) * p.alpha;
+                if (p.act) v = v > 0.f ? v : v * p.slope;
+                if (EM & 8) v *= ((sg >> (8 * g + 4 * h + i)) & 1u) ? 1.f : p.mslope;
+                if (EM & 16) mine |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + i);
+                o[i] = from_f<T>(v);
+            }
+            if (xok) *(bf16x4*)(yp + lch0 + 16 * g) = o;
+        }
+        if (EM & 16) {
+            const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
+            if (xok && h == 0) ((unsigned*)p.sgn_out)[pix] = mine | other;
+        }
+    }
+}
+
 // Half-row (16 pixels) variant for kernels whose free LDS slot is small: transpose space = 16 * (COT*4+16) bytes per wave.
 template <typename T, int MT, int PT>
 __device__ __forceinline__ void conv_epilogue_lds_half(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, int half, char* lds_wave,
