@@ -382,7 +382,8 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
                 if (EM & 16) mine |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + i);
                 o[i] = from_f<T>(v);
             }
-            if (xok) *(bf16x4*)(yp + lch0 + 16 * g) = o;
+            if (xok && !(p.dbg & 32)) *(bf16x4*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
+            if (p.dbg & 32) asm volatile("" :: "v"(o));
         }
         if (EM & 16) {
             const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
