@@ -221,10 +221,10 @@ __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, 
 // holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
 // 2.6 us per chunk against 1.2 us of MFMA), and the weights are 18 of the 57 KiB a stage moves.  Needs ctiles == 1 and
 // nchunk * 18 KiB + two halo stages within 160 KiB (Cin <= 128 in bf16).
-template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG = 2>
-__global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
+template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG = 2, int PT = 2>
+__global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
-    constexpr int NWV = 8, PT = 2;
+    constexpr int NWV = 16 / PT;      // MFMA waves: PT output rows each, 16 rows per unit
     constexpr int TH = PT * NWV, TW = 32, IHT = TH + 2, IWT = TW + 2;
     constexpr int COT = 32 * MT, NTAP = 9;
     constexpr int NHP = IHT * IWT;
@@ -404,9 +404,9 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
 #ifndef SG_PD
 #define SG_PD 2
 #endif
-    constexpr int PD = SG_PD, NRB = PD + 1, NRA = 6;
+    constexpr int PD = SG_PD, NRB = PD + 1, NRA = 3 * (PT - 1) + 1 + PD;      // a tap's fragment is live from its first group to 3 (PT - 1) groups later
     constexpr int NGRP = (PT + 2) * 3, NG2 = 2 * NGRP;               // groups per k-half / per chunk
-    static_assert(PT == 2 && PD >= 1 && PD <= 2, "A-ring size assumes PT == 2 and PD <= 2");
+    static_assert((PT == 2 || PT == 4) && PD >= 1 && PD <= 2, "A-ring sizing");
     // byte offsets inside a stage (stage 0), k-half 0; k-half 1 is the same address with bit 5 flipped (slot ^ 2)
     int pb[NGRP], pa;
     {
@@ -513,12 +513,12 @@ __global__ __launch_bounds__((8 + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     }
 }
 
-template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG = 2>
+template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG = 2, int PT = 2>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
     constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
     static_assert(NSTG == 2 || WRES, "three stages only beside resident weights");
-    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG>;
+    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG, PT>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -534,7 +534,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W8+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -545,7 +545,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
 #else
     q.trace = nullptr;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((8 + NLW) * 64), SMEM, st, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((16 / PT + NLW) * 64), SMEM, st, q);
 #ifdef SG_TRACE
     {
         static int dumps = 0;
@@ -639,6 +639,8 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
                 if (em == 8) return launch_ls<T, 1, 8, true, 8, 3>(p, 1, st);
                 if (em == 16) return launch_ls<T, 1, 8, true, 16, 3>(p, 1, st);
             }
+            // (PT = 4: four MFMA waves with 4 rows each read 36 % fewer fragments per MFMA, but one MFMA wave per SIMD does not
+            //  keep the matrix pipe fed: 96->32 68 -> 74 us, 128->32 90 -> 98 us.  launch_ls<T, 1, 8, true, EM, 2, 4> to retry.)
             if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) {
                 if (em == 0) return launch_ls<T, 1, 8, true, 0>(p, 1, st);
                 if (em == 4) return launch_ls<T, 1, 8, true, 4>(p, 1, st);
