@@ -323,7 +323,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             const char* bx = xb0 + org * p.xpix + c * cstride;
             const char* bw = (const char*)p.wp + ((size_t)uct * p.nchunk + c) * NTAP * COT * 64;
             const int cls = (uty == 0 ? 0 : uty == p.tiles_y - 1 ? 2 : 1) * 3 + (utx == 0 ? 0 : utx == p.tiles_x - 1 ? 2 : 1);
-#ifndef SG_HACK_NOHALO
+#ifndef SG_EXP_NO_HALO_DMA       // timing experiment: skip the halo stream
 #define SG_ISSUE_CLASS(K)                                                                             \
             case K:                                                                                   \
                 _Pragma("unroll") for (int it = 0; it < HIT; ++it)                                     \
@@ -336,7 +336,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             }
 #undef SG_ISSUE_CLASS
 #endif
-#ifndef SG_HACK_NOW
+#ifndef SG_EXP_NO_WEIGHT_DMA     // timing experiment: skip the per-chunk weight stream
             if constexpr (!WRES) {
 #pragma unroll
                 for (int it = 0; it < WIT; ++it)
