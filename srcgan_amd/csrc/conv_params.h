@@ -272,6 +272,25 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
     static_assert(!(SGI || SGO) || (MT == 1 && EPP == 8), "sign masks: 32 output channels, 8 per lane");
     const long ls = (long)lx * 4 + (c0 >> 3);          // mask byte of this lane's 8 channels
     const int xrem = p.OW - ox0 - lx;                // pass k is in range iff k * PPP < xrem
+    // 64-row tiles (conv5 / block-input gradient: residual operands, 168-VGPR budget): the residual operands of ALL rows
+    // and passes are requested before the first row is processed.  Per-row requests exposed one memory latency per row --
+    // traced 4.2 us of epilogue per 25 us unit at 192->64 -- and the second residual was loaded at its use, once per pass.
+    constexpr bool PFALL = MT == 2 && PF && (EM & 3) != 0 && (EM & ~3) == 0;
+    vecT r1a[PFALL ? PT : 1][PFALL ? NP : 1];      // (the second residual per row: both for all rows would spill)
+    if constexpr (PFALL) {
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const int oy = oy0 + q;
+            const bool rok = cok && oy < p.OH;
+            const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const bool ok = rok && pass * PPP < xrem;
+                const long px = rowpix + pass * (long)PPP * p.os;
+                if (use_r1 && ok) r1a[q][pass] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int oy = oy0 + q;
@@ -280,8 +299,14 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
         const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
         const long pstep = (long)PPP * p.os;
         vecT r1v[NPF], mzv[NPF];
+        vecT r2row[PFALL ? NP : 1];
         unsigned sgv[NPF];
-        if (PF) {
+        if constexpr (PFALL) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass)
+                if (use_r2 && rok && pass * PPP < xrem) r2row[pass] = *(const vecT*)((const char*)p.r2 + (rowpix + pass * pstep) * p.r2pix + l2);
+        }
+        if (PF && !PFALL) {
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const bool ok = rok && pass * PPP < xrem;
@@ -316,9 +341,13 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
             if (use_r1) {
+                const vecT t = PFALL ? r1a[PFALL ? q : 0][PFALL ? pass : 0] : r1v[pass % NPF];
 #pragma unroll
-                for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(r1v[pass % NPF][i]); }
-            if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + px * p.r2pix + l2);
+                for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
+            if (use_r2) {
+                vecT t;
+                if constexpr (PFALL) t = r2row[pass];
+                else t = *(const vecT*)((const char*)p.r2 + px * p.r2pix + l2);
 #pragma unroll
                 for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
             if (p.act) {
