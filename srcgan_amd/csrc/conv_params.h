@@ -290,6 +290,11 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
                 if (use_r1 && ok) r1a[q][pass] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
             }
         }
+        // One explicit wait for these loads.  Without it the compiler puts `s_waitcnt vmcnt(0)` at the head of EVERY pass (the
+        // passes are exec-masked blocks and its pending-load state is merged conservatively at their joins), and on gfx9
+        // vmcnt counts stores too: each pass then waited for the previous pass's store to be acknowledged by memory
+        // (~0.45 us each, 3.6 us per unit: the ISA showed the waits, the trace the time).
+        if (!(EM & 2)) __builtin_amdgcn_s_waitcnt(0x0f70);
     }
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
@@ -305,6 +310,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass)
                 if (use_r2 && rok && pass * PPP < xrem) r2row[pass] = *(const vecT*)((const char*)p.r2 + (rowpix + pass * pstep) * p.r2pix + l2);
+            if (EM & 2) __builtin_amdgcn_s_waitcnt(0x0f70);      // once per row (also the previous row's stores), not once per pass
         }
         if (PF && !PFALL) {
 #pragma unroll
@@ -390,13 +396,21 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
     const bool xok = ox < p.OW;
     // the 32 channels of the slice lie inside one 64-byte chunk (ycoff % 32 == 0 for blocked tensors; interleaved: linear)
     const long lch0 = (long)chan_off<T>(p.ycoff + 4 * h, p.yplane);
+    // every row's sign word is requested before the first store: vmcnt counts stores too on gfx9, a load issued after a
+    // row's stores could only be waited for together with them
+    unsigned sgr[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        sgr[q] = 0xffffffffu;
+        if ((EM & 8) && xok && oy0 + q < p.OH) sgr[q] = ((const unsigned*)p.sgn_in)[((long)b * p.OH + oy0 + q) * p.OW + ox];
+    }
+    if (EM & 8) __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int oy = oy0 + q;
         if (oy >= p.OH) continue;                         // wave-uniform
         const long pix = ((long)b * p.OH + oy) * p.OW + ox;
-        unsigned sg = 0xffffffffu;
-        if ((EM & 8) && xok) sg = ((const unsigned*)p.sgn_in)[pix];
+        const unsigned sg = sgr[q];
         char* yp = (char*)p.y + pix * p.ypix;
         unsigned mine = 0u;
 #pragma unroll
