@@ -92,6 +92,12 @@ class _RddbFn(torch.autograd.Function):
             raise ValueError(f"RDDBNet expects [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
         B, _, H, W = x.shape
+        if B == 0:          # an empty batch yields an empty output and zero gradients, as aten::convolution does
+            f0 = (up if down == 0 else 1)
+            ctx.empty = True
+            ctx.save_for_backward(*params)
+            return x.new_zeros((0, out_ch) + ((H * f0, W * f0) if down <= 1 else (H // down, W // down)))
+        ctx.empty = False
         cfg = N.RddbCfg(in_ch, out_ch, up, nf, nb, gc, B, H, W, dtype, down, legacy)
         for p in params:
             N.require_cuda(p, "RDDBNet parameter")
@@ -113,6 +119,8 @@ class _RddbFn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = N.lib()
         params = list(ctx.saved_tensors)
+        if ctx.empty:
+            return (None, None, *[torch.zeros_like(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(params)])
         cfg = ctx.cfg
         if ctx.ws is None:
             raise RuntimeError("RDDBNet backward called twice (activations were released)")

@@ -376,3 +376,14 @@ def test_stacked_generators_x8_vs_oracle():
     for net, ref in ((g1, r1), (g2, r2)):
         for k, p in net.named_parameters():
             assert rel_err(p.grad.cpu(), ref[k].grad) < F32_TOL, k
+
+
+def test_empty_batch_generator():
+    """An empty batch gives an empty output of the right shape and zero parameter gradients (aten::convolution's behaviour on
+    the reference side), not a kernel launch."""
+    from srcgan_amd import RDDBNet
+    net = RDDBNet(3, 3, 4, nf=16, nb=1, gc=8, dtype="fp32").cuda()
+    y = net(torch.zeros(0, 3, 8, 12, device="cuda"))
+    assert tuple(y.shape) == (0, 3, 32, 48)
+    y.sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
