@@ -449,6 +449,9 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             // flat group index G = ks * NGRP + i * 3 + kx
             auto read_b = [&](int G) {
                 const int ks = G / NGRP, g = G % NGRP;
+#ifdef SG_EXP_B_KX0_ONLY       // timing experiment (wrong results): only the kx = 0 pixel fragments are read -- what cross-lane
+                if (g % 3 != 0) return;      // shifts instead of the kx = 1, 2 reads could gain at most
+#endif
                 fb[G % NRB] = *(const frag_t*)(ls + (pb[g] ^ (ks * 32)));
             };
             auto read_a = [&](int G) {                   // the weight tap first used by group G (none for the last input row)
