@@ -406,7 +406,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #endif
     constexpr int PD = SG_PD, NRB = PD + 1, NRA = 3 * (PT - 1) + 1 + PD;      // a tap's fragment is live from its first group to 3 (PT - 1) groups later
     constexpr int NGRP = (PT + 2) * 3, NG2 = 2 * NGRP;               // groups per k-half / per chunk
-    static_assert((PT == 2 || PT == 4) && PD >= 1 && PD <= 2, "A-ring sizing");
+    static_assert((PT == 2 || PT == 4) && PD >= 1 && PD <= 5, "A-ring sizing");
     // byte offsets inside a stage (stage 0), k-half 0; k-half 1 is the same address with bit 5 flipped (slot ^ 2)
     int pb[NGRP], pa;
     {
@@ -452,10 +452,16 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #ifdef SG_EXP_B_KX0_ONLY       // timing experiment (wrong results): only the kx = 0 pixel fragments are read -- what cross-lane
                 if (g % 3 != 0) return;      // shifts instead of the kx = 1, 2 reads could gain at most
 #endif
+#ifdef SG_EXP_NO_FRAG_READS    // timing experiment: MFMAs on stale registers, no LDS fragment reads at all
+                return;
+#endif
                 fb[G % NRB] = *(const frag_t*)(ls + (pb[g] ^ (ks * 32)));
             };
             auto read_a = [&](int G) {                   // the weight tap first used by group G (none for the last input row)
                 const int ks = G / NGRP, g = G % NGRP;
+#ifdef SG_EXP_NO_FRAG_READS
+                return;
+#endif
                 if (g < 9) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -481,7 +487,11 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
                             for (int jj = 0; jj < 4; ++jj)
                                 acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ta][m][jj], fb[G % NRB][jj], acc[m][q], 0, 0, 0);
                         } else {
+#ifdef SG_EXP_NO_MFMA_INSTR    // timing experiment: fragment reads kept alive, no MFMA instructions
+                            asm volatile("" :: "v"(fa[ta][m]), "v"(fb[G % NRB]));
+#else
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta][m], fb[G % NRB], acc[m][q], 0, 0, 0);
+#endif
                         }
                     }
                 }
