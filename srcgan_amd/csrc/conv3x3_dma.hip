@@ -364,7 +364,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #pragma unroll
         for (int k = 0; k < NSTG - 1; ++k) ahead = issue_next();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the LDS bias copy
-        int trk = 0;
+        [[maybe_unused]] int trk = 0;
         for (int u = u0; u < u_hi; u += gw) {
             for (int c = 0; c < p.nchunk; ++c) {
 #ifdef SG_TRACE
@@ -419,7 +419,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         pa = (WRES ? NSTG * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
     }
     int stage = 0;
-    int trk = 0;
+    [[maybe_unused]] int trk = 0;
     for (int u = u0; u < u_hi; u += gw) {
         const int cct = u % p.ctiles; int t = u / p.ctiles;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
