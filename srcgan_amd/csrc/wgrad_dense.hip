@@ -18,6 +18,7 @@ struct WdP {
     int B, H, W, G, C, dycoff, xcoff;
     long dypix, dyplane, xpix, xplane;       // bytes; see conv_params.h (interleaved NHWC: plane = 64)
     int g_base;                 // first gradient channel of this launch's row group
+    int cin_lim[4];             // per 32-row block of the group: input channels some segment needs (blocks above the dense connectivity's triangle are skipped)
     int nsplit, tiles_x, tiles_y, ntiles, ncit, want_bias;
     unsigned long long* trace;       // diagnostic (SG_TRACE builds): per-tile-step timestamps of one workgroup
 };
@@ -243,6 +244,15 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
         if (split >= p.nsplit) return;
     }
     const bool do_bias = wn == 0 && cit == 0 && p.want_bias;
+    // 32x32 blocks no convolution of the dense block needs (conv m reads only the first 64 + 32 (m - 1) channels): the wave still
+    // issues its share of the DMA and joins the barriers, but reads no fragments and issues no MFMAs -- 6 of the 32 blocks of a
+    // dense block's two launches.  The step gets no shorter for it (another SIMD pair still has two busy waves); the kernel
+    // runs power-limited, and the matrix pipe's energy is what the clock is traded against.
+#ifdef SG_WD_NO_SKIP
+    const bool useful = true;
+#else
+    const bool useful = (cit * NT + wn) * 32 < p.cin_lim[wm] || do_bias;
+#endif
 
     // ---- per-wave piece table: per-lane offset from the tile origin, channel-plane offset (uniform), border class
     int voff[IPW], soff[IPW];
@@ -328,6 +338,13 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
 #endif
         const bool more = t + 1 < t_end;
         if (more) { advance(); origin(); }
+        if (!useful) {
+            if (more && !(SG_WD_EXP & 1)) {
+#pragma unroll
+                for (int it = 0; it < IPW; ++it) piece(it, stage ^ 1);
+            }
+            continue;
+        }
         const char* my_d = smem + stage * SBYTES + wm * DBYTES;
         const char* my_x = smem + stage * SBYTES + MT * DBYTES + wn * XBYTES;
         // Row-ordered: the TH*2 gradient fragments a[py][xh] of the tile are read once; an input fragment b(i, kx, xh)
@@ -613,6 +630,12 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
         static const bool nt2_only = getenv("SRCGAN_WD_NT2") != nullptr;
         const int nt = nt2_only ? 2 : wd_nt(mt, cin_max, d->dtype);
         p.g_base = g_base; p.ncit = cdiv(cin_max, 32 * nt); p.want_bias = want_bias;
+        for (int b = 0; b < 4; ++b) {
+            p.cin_lim[b] = 0;
+            for (int k = 0; k < d->nseg; ++k)
+                if (d->seg[k].grad && d->seg[k].g0 < g_base + 32 * (b + 1) && d->seg[k].g1 > g_base + 32 * b && d->seg[k].Cin > p.cin_lim[b])
+                    p.cin_lim[b] = d->seg[k].Cin;
+        }
         p.nsplit = wd_nsplit(mt, nt, p.ncit, d->dtype, d->B, d->H, d->W);
         int ns = 0;
         if (d->dtype == SRCGAN_F32) SG_TRY(dispatch_wd<float>(p, mt, nt, st, ns));
