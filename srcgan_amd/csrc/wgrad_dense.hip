@@ -501,8 +501,14 @@ static int launch_wd(WdP p, hipStream_t st) {
     snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d%s>", sizeof(T) == 4 ? "f32" : "bf16", MT, NT, fast ? ",fast" : "");
     const double px = (double)p.B * p.H * p.W;
     const int rows = (p.G - p.g_base) < 32 * MT ? (p.G - p.g_base) : 32 * MT;
-    const int tok = sg_prof_start(cls, 2.0 * px * 9 * rows * (double)(p.ncit * 32 * NT < p.C ? p.ncit * 32 * NT : p.C),
-                                  px * (rows + p.C) * sizeof(T), st);
+    // algorithmic work = the (gradient channel, input channel) pairs some convolution of the block owns (the triangle), not
+    // the rectangle the workgroups cover
+    double pairs = 0.0;
+    for (int b = 0; b < MT; ++b) {
+        const int rb = rows - 32 * b < 32 ? rows - 32 * b : 32;
+        if (rb > 0) pairs += (double)rb * (p.cin_lim[b] < p.C ? p.cin_lim[b] : p.C);
+    }
+    const int tok = sg_prof_start(cls, 2.0 * px * 9 * pairs, px * (rows + p.C) * sizeof(T), st);
 #ifdef SG_TRACE
     static unsigned long long* trace = nullptr;
     if (!trace) SG_HIP(hipMalloc(&trace, 64 * 4 * 8));
