@@ -4,8 +4,10 @@
 
 One "step" = one paired optimisation step on one synthetic batch resident in HBM:
   G-step {G fwd, D(fake) fwd + dgrad, L1*10 + lsgan, G bwd, Adam} + D-step {D(real), D(fake.detach()) fwd/bwd, Adam}
-(SURVEY.md section 8d).  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch through
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
+(SURVEY.md section 8d).  `python bench.py --gpus N --steps K --warmup W`: with N > 1 and no WORLD_SIZE in the
+environment this process only LAUNCHES -- it starts N fresh rank processes (one per GPU, RCCL over xGMI, rendezvous on
+127.0.0.1) before anything touches a GPU, relays rank 0's JSON line and exits non-zero if a rank fails.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE set) it is a rank.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -114,6 +116,48 @@ def pmc_traffic(cls):
     return None
 
 
+def launch_ranks(n):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: N child rank processes, one per device.
+    The parent never initialises a GPU (no exec of a GPU-holding process, no fork after HIP init): children are fresh
+    interpreters with the torchrun environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import socket
+    import subprocess
+    if os.environ.get("SRCGAN_LOCAL_DEVICE") is None:        # (rehearsal on one device: tests/test_gpu_dist.py)
+        have = torch.cuda.device_count()                      # counting devices does not initialise HIP
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs, rc = [], 0
+    with tempfile.TemporaryFile(mode="w+") as cap:               # rank 0's stdout (a pipe would need a reader thread)
+        try:
+            for r in range(n):
+                env = dict(os.environ)
+                env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, cwd=ROOT,
+                                              stdout=cap if r == 0 else subprocess.DEVNULL))
+            while any(p.poll() is None for p in procs):
+                if any(p.poll() not in (None, 0) for p in procs):    # a failed rank leaves its peers waiting in a collective
+                    break
+                time.sleep(0.1)
+            rc = next((p.returncode for p in procs if p.returncode not in (None, 0)), 0)
+        finally:
+            for p in procs:                                      # end exactly the processes started here
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+        cap.seek(0)
+        out0 = cap.read()
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if rc != 0 or len(lines) != 1:
+        sys.stdout.write(out0)
+        raise SystemExit(rc or 1)
+    print(lines[0], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
 
     from srcgan_amd import dist as sdist
     from srcgan_amd import _native as N

@@ -103,6 +103,11 @@ typedef struct srcgan_conv_desc {
      *   sign_in : read instead of mz:  v *= bit ? 1 : mslope
      * A descriptor that sets either and does not meet the conditions is refused (no silent fallback). */
     void* sign_out; const void* sign_in;
+    /* y_f32: the output tensor is f32 whatever `dtype` says (y_cs still counts elements).  Set on the input-gradient convolutions
+     * whose result enters a BatchNorm / GroupNorm backward projection: g - mean(g) - xhat*mean(g*xhat) cancels most of g, so g is
+     * rounded to the compute dtype only after it.  r1_f32: the r1 residual operand is f32 likewise.  Kernels that do not
+     * implement a requested combination refuse the descriptor. */
+    int y_f32, r1_f32;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 
@@ -159,6 +164,8 @@ int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream);
  *   mode 0: out0[c] = scale * sum a[p,c]                         (bias grad; BN mean)
  *   mode 1: out0[c] = scale * sum (a[p,c]-m[c])^2                (BN variance)
  *   mode 2: out0[c] = sum g[p,c] ; out1[c] = sum g[p,c]*(z[p,c]-m[c])*rstd[c]   (BN backward)
+ *   mode 3: mode 2 with g stored as f32 whatever `dtype` says (z stays dtype): the gradient entering a BatchNorm backward
+ *           of a bf16 network is kept in f32 until after the projection (most of it is common-mode and cancels there)
  * scratch: 2*nblk*C floats, nblk = srcgan_col_reduce_blocks(npix).
  * ------------------------------------------------------------------------- */
 int srcgan_col_reduce_blocks(long npix);
@@ -178,7 +185,7 @@ int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, const float
                           const float* beta, long npix, int C, int cs, float slope, int dtype, void* stream);
 int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mean, const float* rstd,
                         const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
-                        int dtype, void* stream);
+                        int g_f32, int dtype, void* stream);      /* g_f32: g is f32 whatever dtype says (then dz != g) */
 
 /* y[p, ycoff+c] = (y + x[p, xcoff+c]) * (mz ? (mz[p, mzcoff+c] > 0 ? 1 : mslope) : 1) for c < C
  * (residual gradient joins; optional LeakyReLU' of the tensor the gradient belongs to) */

@@ -6,7 +6,7 @@ set -e
 ROOT=$(cd $(dirname $0)/.. && pwd)
 NAME=$1; FILE=$2; shift 2
 V=$ROOT/srcgan_amd/lib/variants; mkdir -p $V
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $ROOT/srcgan_amd/csrc/$FILE -o $V/$NAME.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSG_DIAG "$@" -c $ROOT/srcgan_amd/csrc/$FILE -o $V/$NAME.o
 OBJS=""
 for o in $ROOT/srcgan_amd/lib/*.o; do
   if [ "$(basename $o .o)" != "$(basename $FILE .hip)" ]; then OBJS="$OBJS $o"; fi

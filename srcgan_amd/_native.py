@@ -55,7 +55,7 @@ class ConvDesc(C.Structure):
                 ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("slope", C.c_float), ("mslope", C.c_float),
                 ("act", C.c_int),
                 ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long), ("rev_batch", C.c_int),
-                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p)]
+                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p), ("y_f32", C.c_int), ("r1_f32", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -121,7 +121,7 @@ SIGNATURES = {
     "srcgan_bn_finalize": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _P]),
     "srcgan_bn_eval_rstd": (_I, [_P, _P, _I, _F, _P]),
     "srcgan_bn_apply_lrelu": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
-    "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
     "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
     "srcgan_gn_scratch_floats": (_S, [_I, _I]),

@@ -55,6 +55,23 @@ __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / 
 __host__ __device__ static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---------------------------------------------------------------- diagnostics
+// The production library carries NO run-time experiment switches: SG_DBG(p, bit) is the constant 0 and sg_env() returns
+// nullptr unless the file is compiled with -DSG_DIAG (scripts/build_variant.sh builds such variants side by side and
+// SRCGAN_AMD_LIB selects one).  Wrong-result timing experiments (SG_EXP_*, SG_WD_EXP, SG_TRACE) are compile-time only.
+#ifdef SG_DIAG
+#include <stdlib.h>
+#define SG_DBG(p, bit) ((p).dbg & (bit))
+static inline const char* sg_env(const char* name) { return getenv(name); }
+#else
+#define SG_DBG(p, bit) 0
+static inline const char* sg_env(const char*) { return nullptr; }
+#if defined(SG_TRACE) || defined(SG_WD_EXP) || defined(SG_EXP_NO_HALO_DMA) || defined(SG_EXP_NO_WEIGHT_DMA) || defined(SG_EXP_B_KX0_ONLY) || \
+    defined(SG_EXP_NO_FRAG_READS) || defined(SG_EXP_NO_MFMA_INSTR)
+#error "timing experiments need -DSG_DIAG (scripts/build_variant.sh adds it)"
+#endif
+#endif
+
 // ---------------------------------------------------------------- optional per-launch profiling
 // (bench.py: HIP events on the launch stream around the hot kernels; off by default -> zero cost)
 int sg_prof_start(const char* cls, double flops, double bytes, hipStream_t st);   // returns token or -1

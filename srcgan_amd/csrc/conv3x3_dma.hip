@@ -127,14 +127,14 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
 
         for (int c = 0; c < p.nchunk; ++c, stage ^= 1) {
             __syncthreads();        // own DMAs into `stage` landed (vmcnt(0)); everyone is done with the other stage
-            if (!(p.dbg & 2)) {
+            if (!SG_DBG(p, 2)) {
                 if (c + 1 < p.nchunk) { if (NLW == 0 || loader) issue(c + 1, stage ^ 1); }
                 else if (u + gw < u_hi) { setup_fetch(u + gw, nb_, nct, noy0, nox0); if (NLW == 0 || loader) issue(0, stage ^ 1); }   // next unit's first chunk
             }
             if (loader) continue;
             const char* lh = smem + stage * SBYTES;
             const char* lw = lh + HBYTES;
-            if (p.dbg & 1) continue;
+            if (SG_DBG(p, 1)) continue;
             // 18 k-steps (9 taps x 2 halves of the 64-byte chunk), software-pipelined: the fragments of step s+1 are
             // requested from LDS before the MFMAs of step s issue, so LDS latency hides under the matrix pipe.
             using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
                 }
             };
             load_step(0, fa[0], fb[0]);
-            const bool skip_rd = p.dbg & 16, skip_mm = p.dbg & 8;
+            const bool skip_rd = SG_DBG(p, 16), skip_mm = SG_DBG(p, 8);
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
                 if (s + 1 < 18 && !skip_rd) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (p.dbg & 4) continue;
+        if (SG_DBG(p, 4)) continue;
         // ---- epilogue of the finished unit; the next unit's first chunk is already in flight into `stage`
         // (the loop increment flipped it), so the transpose space is the OTHER stage = the one just computed from.
         if (p.vec16) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #ifdef SG_TRACE
                 const unsigned long long t_bar = __builtin_amdgcn_s_memrealtime();
 #endif
-                if (p.dbg & 2) continue;
+                if (SG_DBG(p, 2)) continue;
                 ahead = issue_next();
 #ifdef SG_TRACE
                 if (p.trace && blockIdx.x == 8 && iw == 0 && lane == 0 && trk < 60) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
                 p.trace[trk * 8 + 4] = t_arr; p.trace[trk * 8 + 5] = __builtin_amdgcn_s_memrealtime(); ++trk;
             }
 #endif
-            if (p.dbg & 1) continue;
+            if (SG_DBG(p, 1)) continue;
             const char* ls = smem + stage * SBYTES;
             const char* lsw = WRES ? smem + c * WCH : ls;
             frag_t fa[NRA][MT], fb[NRB];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         }
         if constexpr (DIRECT) {
             if (direct_ok) {
-                if (!(p.dbg & 4)) conv_epilogue_direct32<PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+                if (!SG_DBG(p, 4)) conv_epilogue_direct32<PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
                 continue;
             }
         }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             const unsigned long long t_eb = __builtin_amdgcn_s_memrealtime();
 #endif
             char* tsp = smem + (stage == 0 ? NSTG - 1 : stage - 1) * SBYTES + wave * (32 * ERS);      // the stage just consumed: refilled only after the next chunk barrier
-            if (!(p.dbg & 4))
+            if (!SG_DBG(p, 4))
                 conv_epilogue_lds_rows<T, MT, PT, EM>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
 #ifdef SG_TRACE
             if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk <= 60) {
@@ -543,7 +543,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     }
     ConvP q = p;
     q.tiles_x = cdiv(p.OW, 32); q.tiles_y = cdiv(p.OH, 16); q.ctiles = ctiles;
-    { static const char* e = getenv("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
+    { static const char* e = sg_env("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
@@ -562,7 +562,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
 #ifdef SG_TRACE
     {
         static int dumps = 0;
-        if (getenv("SRCGAN_TRACE") && dumps < 3) {
+        if (sg_env("SRCGAN_TRACE") && dumps < 3) {
             ++dumps;
             unsigned long long h[60 * 8];
             SG_HIP(hipStreamSynchronize(st));
@@ -597,7 +597,7 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
         attr_set = true;
     }
     ConvP q = p;
-    { static const char* e = getenv("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
+    { static const char* e = sg_env("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
     q.tiles_x = cdiv(p.OW, 32);
     q.tiles_y = cdiv(p.OH, TH);
     q.ctiles = ctiles;
@@ -625,7 +625,7 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
 
 template <typename T>
 static int dispatch_dma(const ConvP& p, hipStream_t st) {
-    static const char* cfg_env = getenv("SRCGAN_DMA_CFG");
+    static const char* cfg_env = sg_env("SRCGAN_DMA_CFG");
     char cfg = cfg_env ? cfg_env[0] : 'l';     // 'l': 8 MFMA + 4 loader waves (default); 'a': 8 self-loading waves
     // the loader-specialised kernel needs a uniform K-chunk stride and 31-bit per-image offsets
     const bool ls_ok = (p.xplane == 0 || p.xcoff % DT<T>::KCE == 0) && (p.Cin % DT<T>::KCE == 0 || p.nchunk == 1) &&
@@ -640,12 +640,12 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
 #endif
         if constexpr (sizeof(T) == 4) return launch_ls<T, 1, 4>(p, 1, st);      // fp32: 128 VGPRs (16 waves) would spill
         else {
-            static const bool no_wres = getenv("SRCGAN_NO_WRES") != nullptr;
+            static const bool no_wres = sg_env("SRCGAN_NO_WRES") != nullptr;
             // resident weights: two 40 KiB halo stages + nchunk * 18 KiB + bias within 160 KiB
             // epilogue operand set: Cout <= 32 convs are the dense-block forward (none) and its gradient slices (mz)
             const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0) | (p.sgn_in ? 8 : 0) | (p.sgn_out ? 16 : 0);
             SG_REQUIRE(em < 8 || em == 8 || em == 16, "conv3x3: a sign mask cannot be combined with other epilogue operands");
-            static const bool no_s3 = getenv("SRCGAN_NO_S3") != nullptr;
+            static const bool no_s3 = sg_env("SRCGAN_NO_S3") != nullptr;
             if (!no_wres && !no_s3 && p.nchunk == 2) {           // Cin = 64: three 40 KiB stages + 36 KiB of weights + bias = 160 KiB
                 if (em == 0) return launch_ls<T, 1, 8, true, 0, 3>(p, 1, st);
                 if (em == 4) return launch_ls<T, 1, 8, true, 4, 3>(p, 1, st);

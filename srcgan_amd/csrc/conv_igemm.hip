@@ -260,7 +260,7 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
 }
 
 int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st);      // conv3x3_dma.hip
-static const bool g_force_generic = getenv("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
+static const bool g_force_generic = sg_env("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
 
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     SG_REQUIRE(d && d->x && d->wp && d->y, "srcgan_conv_igemm: null pointer");
@@ -287,8 +287,10 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.r2coff = d->r2_coff; p.r2cend = d->r2_cend;
     p.mzcoff = d->mz_coff; p.mzc0 = d->mz_c0;
     auto pl = [](long v) { return v ? v : 64L; };      // plane stride 0 = interleaved NHWC
-    p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * esz; p.yplane = pl(d->y_plane);
-    p.r1pix = (long)d->r1_cs * esz; p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
+    p.yf32 = d->y_f32 != 0 && esz != 4; p.r1f32 = d->r1_f32 != 0 && esz != 4;
+    SG_REQUIRE(!(p.yf32 || p.r1f32) || (!d->y_plane && !d->r1_plane), "srcgan_conv_igemm: f32 output / residual operands are interleaved NHWC only");
+    p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * (p.yf32 ? 4 : esz); p.yplane = pl(d->y_plane);
+    p.r1pix = (long)d->r1_cs * (p.r1f32 ? 4 : esz); p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
     p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
     p.rev = d->rev_batch;
     p.sgn_out = (unsigned char*)d->sign_out; p.sgn_in = (const unsigned char*)d->sign_in;

@@ -48,7 +48,7 @@ struct Conv {
     Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
     // consecutive 3x3 s1 launches walk the batch in alternating directions (SRCGAN_NO_ZIGZAG=1 disables): see srcgan_conv_desc.rev_batch
     int run(void* st) {
-        static const bool zig = getenv("SRCGAN_NO_ZIGZAG") == nullptr;
+        static const bool zig = sg_env("SRCGAN_NO_ZIGZAG") == nullptr;
         static int flip = 0;
         if (zig && d.kh == 3 && d.kw == 3 && d.stride == 1) { d.rev_batch = flip; flip ^= 1; }
         return srcgan_conv_igemm(&d, st);
@@ -183,7 +183,7 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     // and of the dense wgrad is then >= 1 KiB contiguous (64-byte pieces at a 384-byte pixel stride ran at half rate)
     P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
     // one bit per element for LeakyReLU' (instead of re-reading the activation in the backward pass): bf16, 32-channel slices
-    static const bool no_sign = getenv("SRCGAN_NO_SIGNMASK") != nullptr || getenv("SRCGAN_DMA_CFG") != nullptr;
+    static const bool no_sign = sg_env("SRCGAN_NO_SIGNMASK") != nullptr || sg_env("SRCGAN_DMA_CFG") != nullptr;
     P.bm_bytes = (!no_sign && c->dtype == SRCGAN_BF16 && c->gc == 32 && c->nf % 32 == 0 && c->legacy != 2) ? (long)B * P.Ht * P.Wt * 4 : 0;
     P.bm = align_up((size_t)P.nplane * P.plane_bytes, 256);
     P.szA = align_up(P.bm + 4 * (size_t)P.bm_bytes, 256);
@@ -683,7 +683,7 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     }
     P.in_cs = img_cs(c->in_ch); P.out_cs = 8;
     const size_t e = P.esz, B = c->B;
-    static const bool no_s2d = getenv("SRCGAN_NO_S2D") != nullptr;
+    static const bool no_s2d = sg_env("SRCGAN_NO_S2D") != nullptr;
     P.s2d = !no_s2d && c->H % 2 == 0 && c->W % 2 == 0;
     Bump b;
     P.xin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);

@@ -479,7 +479,7 @@ static int launch_wd(WdP p, hipStream_t st) {
     bool fast = false;
     if constexpr (!std::is_same<T, float>::value) {
         // whole tiles, 32-channel-aligned slices when planar, and every byte offset within 31 bits
-        static const bool no_fast = getenv("SRCGAN_WD_SLOW") != nullptr;
+        static const bool no_fast = sg_env("SRCGAN_WD_SLOW") != nullptr;
         const double span_dy = p.dyplane != 64 ? (double)p.dyplane * cdiv(p.dycoff + p.G, 32) : (double)p.B * p.H * p.W * p.dypix;
         const double span_x = p.xplane != 64 ? (double)p.xplane * cdiv(p.xcoff + p.C, 32) : (double)p.B * p.H * p.W * p.xpix;
         fast = !no_fast && p.H % TH == 0 && p.W % 32 == 0 && span_dy < 2.0e9 && span_x < 2.0e9 &&
@@ -519,7 +519,7 @@ static int launch_wd(WdP p, hipStream_t st) {
 #ifdef SG_TRACE
     {
         static int dumps = 0;
-        if (getenv("SRCGAN_TRACE") && dumps < 2 && fast) {
+        if (sg_env("SRCGAN_TRACE") && dumps < 2 && fast) {
             ++dumps;
             unsigned long long h[64 * 4];
             SG_HIP(hipStreamSynchronize(st));
@@ -633,7 +633,7 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
         p.B = d->B; p.H = d->H; p.W = d->W; p.G = d->G; p.C = d->C;
         p.dycoff = d->dy_coff; p.xcoff = d->x_coff;
         p.dypix = (long)d->dy_cs * esz; p.dyplane = d->dy_plane ? d->dy_plane : 64; p.xpix = (long)d->x_cs * esz; p.xplane = d->x_plane ? d->x_plane : 64;
-        static const bool nt2_only = getenv("SRCGAN_WD_NT2") != nullptr;
+        static const bool nt2_only = sg_env("SRCGAN_WD_NT2") != nullptr;
         const int nt = nt2_only ? 2 : wd_nt(mt, cin_max, d->dtype);
         p.g_base = g_base; p.ncit = cdiv(cin_max, 32 * nt); p.want_bias = want_bias;
         for (int b = 0; b < 4; ++b) {

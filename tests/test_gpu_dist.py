@@ -96,3 +96,21 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
     assert line["roofline"] is not None and line["cpu_baseline"] is None
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the parent starts two
+    fresh rank processes before touching a GPU, relays rank 0's single JSON line.  One-device rehearsal over gloo."""
+    env = dict(os.environ)
+    env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SRCGAN_FORCE_DIST"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "2", "--nb", "1", "--lr-size", "64"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
+    assert line["config"]["parallelism"] == "dp2" and line["cpu_baseline"] is None

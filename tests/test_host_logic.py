@@ -213,3 +213,22 @@ def test_input_pipeline_needs_the_device():
     from srcgan_amd import data as D
     with pytest.raises(RuntimeError):
         D.arr2lab(torch.zeros(4, 4, 3, dtype=torch.uint8))
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """`python bench.py --gpus 2` without WORLD_SIZE is the launcher: with no GPU here the rank processes exit non-zero
+    ("needs an MI355X") and the parent must pass that on instead of hanging or printing a JSON line."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "only 0 GPU" in out.stderr
+    env["SRCGAN_LOCAL_DEVICE"] = "0"          # skip the device count: the ranks themselves fail
+    env["SRCGAN_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "MI355X" in out.stderr
