@@ -187,6 +187,13 @@ int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mea
                         const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
                         int g_f32, int dtype, void* stream);      /* g_f32: g is f32 whatever dtype says (then dz != g) */
 
+/* Input gradient of a ONE-output-channel stride-1 convolution (PatchGAN's prediction layer, model/model.py:634), all f32:
+ *   g[b,y,x,c] = (act ? (act[b,y,x,c] > 0 ? 1 : mslope) : 1) * sum_{ky,kx} dy[b, y+pad-ky, x+pad-kx] * w[0][c][ky][kx]
+ * dy: f32 [B][OH][OW] (the NCHW gradient as autograd hands it over), w: canonical f32 [1][C][kh][kw], act: NHWC activation of
+ * `dtype` (dense, cs == C) or null, g: f32 NHWC [B][H][W][C].  4x4 kernels; C/4 must divide 256. */
+int srcgan_conv1_dgrad_f32(const float* dy, const float* w, const void* act, float* g, int B, int H, int W, int OH, int OW,
+                           int C, int kh, int kw, int pad, float mslope, int dtype, void* stream);
+
 /* y[p, ycoff+c] = (y + x[p, xcoff+c]) * (mz ? (mz[p, mzcoff+c] > 0 ? 1 : mslope) : 1) for c < C
  * (residual gradient joins; optional LeakyReLU' of the tensor the gradient belongs to) */
 int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, int x_cs, int x_coff,
@@ -208,7 +215,9 @@ int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void
                       float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream);
 int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
                        void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
-                       float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream);
+                       float slope, int B, long hw, int C, int G, int dy_f32, int dres_f32, int dtype, float* scratch, void* stream);
+/* dy_f32 / dres_f32: dy / dres hold f32 elements whatever dtype says (their channel strides still count elements): the gradient
+ * entering a normalisation backward is rounded to the compute dtype only after the projection. */
 
 /* x2 nearest up-sampling of an NHWC feature map (src may be a channel slice of a blocked buffer: s_plane != 0) and its
  * adjoint: dst[y][x] = sum of the 2x2 block of src, times LeakyReLU'(mz[y][x]) when mz is given.  Replaces

@@ -33,8 +33,40 @@ __all__ = [
     "paired_step", "PairedStepState", "make_paired_state", "rddbneta_forward",
     "rddbneta_state", "cycle_step", "CycleState", "make_cycle_state", "cosine_lr_sequence",
     "rddbnetb_forward", "legacy_rddbnet_forward", "legacy_keys", "resdeconv_forward", "espcn_forward", "srcnn_forward", "edsr_forward", "srdn_forward", "metric_ae", "metric_ssim",
-    "arr2gray", "arr2rgb", "arr2lab", "arr2ab", "lab2img",
+    "arr2gray", "arr2rgb", "arr2lab", "arr2ab", "lab2img", "storage",
 ]
+
+
+# ---------------------------------------------------------------------------
+# Storage-dtype emulation (test infrastructure for the bf16 perf mode).
+# The native bf16 mode STORES activations and packed conv weights in bf16 (f32 accumulate, f32 biases / norm parameters /
+# statistics).  ``with storage(torch.bfloat16):`` makes the forward functions below round at exactly those storage points
+# (straight-through for autograd: the backward stays f32), so a test can separate what bf16 storage does to a result --
+# present in ANY bf16 implementation, and amplified by ill-conditioned steps such as a BatchNorm backward behind a constant
+# lsgan label -- from what the kernels add to it.  Default: no rounding, the functions are the reference's arithmetic.
+# ---------------------------------------------------------------------------
+_STORAGE = None
+
+
+class storage:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _STORAGE
+        self._old, _STORAGE = _STORAGE, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        global _STORAGE
+        _STORAGE = self._old
+
+
+def _st(t: Tensor) -> Tensor:
+    """value as the native path holds it in HBM (identity unless inside ``storage(dtype)``)."""
+    if _STORAGE is None or t is None:
+        return t
+    return t + (t.to(_STORAGE).to(t.dtype) - t).detach()
 
 
 # ---------------------------------------------------------------------------
@@ -50,18 +82,21 @@ def rdb_forward(sd: State, pre: str, x: Tensor) -> Tensor:
     feats = [x]
     for k in range(1, 6):
         inp = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
-        y = F.conv2d(inp, sd[f"{pre}conv{k}.weight"], sd[f"{pre}conv{k}.bias"], 1, 1)
+        y = F.conv2d(inp, _st(sd[f"{pre}conv{k}.weight"]), sd[f"{pre}conv{k}.bias"], 1, 1)
         if k < 5:
-            feats.append(_lrelu(y))
+            feats.append(_st(_lrelu(y)))
     return y * RES_SCALE + x
 
 
 def rrdb_forward(sd: State, pre: str, x: Tensor) -> Tensor:
-    """RRDB.forward, rddb.py:78-82: three dense blocks, out = 0.2*out + x."""
+    """RRDB.forward, rddb.py:78-82: three dense blocks, out = 0.2*out + x.
+    (Storage emulation: the native conv5 epilogue stores a block's output once; RDB3's store already includes the RRDB skip.)"""
     out = x
     for j in (1, 2, 3):
         out = rdb_forward(sd, f"{pre}RDB{j}.", out)
-    return out * RES_SCALE + x
+        if j < 3:
+            out = _st(out)
+    return _st(out * RES_SCALE + x)
 
 
 def rddbnet_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
@@ -69,16 +104,16 @@ def rddbnet_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
     Up-sampler: ConvTranspose2d(k=2,s=2,p=0,no bias)+LeakyReLU per x2 stage
     (rddb.py:9-38,93-97)."""
     nb = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("RRDB_trunk."))
-    fea = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], 1, 1)
+    fea = _st(F.conv2d(_st(x), _st(sd["conv_first.weight"]), sd["conv_first.bias"], 1, 1))
     t = fea
     for i in range(nb):
         t = rrdb_forward(sd, f"RRDB_trunk.{i}.", t)
-    t = F.conv2d(t, sd["trunk_conv.weight"], sd["trunk_conv.bias"], 1, 1)
-    fea = fea + t
+    t = F.conv2d(t, _st(sd["trunk_conv.weight"]), sd["trunk_conv.bias"], 1, 1)
+    fea = _st(fea + t)
     if upscale_factor != 1:
         for s in range(int(math.log2(upscale_factor))):
-            fea = _lrelu(F.conv_transpose2d(fea, sd[f"upscale_layers.{2 * s}.weight"], None, 2, 0))
-    return F.conv2d(fea, sd["conv_last.weight"], None, 1, 1)
+            fea = _st(_lrelu(F.conv_transpose2d(fea, _st(sd[f"upscale_layers.{2 * s}.weight"]), None, 2, 0)))
+    return _st(F.conv2d(fea, _st(sd["conv_last.weight"]), None, 1, 1))
 
 
 def rddbnetb_forward(sd: State, x: Tensor, mode: str) -> Tensor:
@@ -141,29 +176,29 @@ def legacy_keys(nb: int, tail) -> List[str]:
 def _rd_block(sd: State, pre: str, x: Tensor, stride: int) -> Tensor:
     """BasicBlock.forward, resdeconv.py:78-97 (GroupNorm(32), ReLU; 1x1 strided conv + GroupNorm shortcut when present)."""
     gn = lambda t, n: F.group_norm(t, 32, sd[pre + n + ".weight"], sd[pre + n + ".bias"], 1e-5)
-    out = F.relu(gn(F.conv2d(x, sd[pre + "conv1.weight"], None, stride, 1), "bn1"))
-    out = gn(F.conv2d(out, sd[pre + "conv2.weight"], None, 1, 1), "bn2")
+    out = _st(F.relu(gn(_st(F.conv2d(x, _st(sd[pre + "conv1.weight"]), None, stride, 1)), "bn1")))
+    out = gn(_st(F.conv2d(out, _st(sd[pre + "conv2.weight"]), None, 1, 1)), "bn2")
     idn = x
     if pre + "downsample.0.weight" in sd:
-        idn = F.group_norm(F.conv2d(x, sd[pre + "downsample.0.weight"], None, stride, 0), 32,
-                           sd[pre + "downsample.1.weight"], sd[pre + "downsample.1.bias"], 1e-5)
-    return F.relu(out + idn)
+        idn = _st(F.group_norm(_st(F.conv2d(x, _st(sd[pre + "downsample.0.weight"]), None, stride, 0)), 32,
+                               sd[pre + "downsample.1.weight"], sd[pre + "downsample.1.bias"], 1e-5))
+    return _st(F.relu(out + idn))
 
 
 def resdeconv_forward(sd: State, x: Tensor) -> Tensor:
     """ResDeconv.forward, resdeconv.py:164-195.  A 1-channel source is replicated to the stem's 3 channels."""
     if x.shape[1] == 1:
         x = torch.cat([x, x, x], dim=1)
-    t = F.relu(F.group_norm(F.conv2d(x, sd["conv1.weight"], None, 2, 3), 32, sd["bn1.weight"], sd["bn1.bias"], 1e-5))
+    t = _st(F.relu(F.group_norm(_st(F.conv2d(_st(x), _st(sd["conv1.weight"]), None, 2, 3)), 32, sd["bn1.weight"], sd["bn1.bias"], 1e-5)))
     for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2), ("layer4", 2)):
         t = _rd_block(sd, f"{name}.0.", t, stride)
         t = _rd_block(sd, f"{name}.1.", t, 1)
     for dc, name in (("deconv10", "upRes1"), ("deconv11", "upRes2"), ("deconv12", "upRes3")):
-        t = F.conv_transpose2d(t, sd[dc + ".weight"], None, 2, 0)
+        t = _st(F.conv_transpose2d(t, _st(sd[dc + ".weight"]), None, 2, 0))
         t = _rd_block(sd, f"{name}.0.", t, 1)
         t = _rd_block(sd, f"{name}.1.", t, 1)
-    t = F.conv_transpose2d(t, sd["deconv13.weight"], None, 2, 0)
-    return F.conv2d(t, sd["pred.weight"], None, 1, 1)
+    t = _st(F.conv_transpose2d(t, _st(sd["deconv13.weight"]), None, 2, 0))
+    return _st(F.conv2d(t, _st(sd["pred.weight"]), None, 1, 1))
 
 
 def espcn_forward(sd: State, x: Tensor, upscale_factor: int) -> Tensor:
@@ -358,18 +393,22 @@ def nlayer_d_forward(sd: State, x: Tensor, training: bool = True) -> Tensor:
     # stride 2 for every conv except the last two (model/model.py:612,620,628,634)
     for n, i in enumerate(conv_ids):
         strides[i] = 2 if n < len(conv_ids) - 2 else 1
-    h = x
+    h = _st(x)
     for i in conv_ids:
-        h = F.conv2d(h, sd[f"model.{i}.weight"], sd.get(f"model.{i}.bias"), strides[i], 1)
+        h = F.conv2d(h, _st(sd[f"model.{i}.weight"]), sd.get(f"model.{i}.bias"), strides[i], 1)
         if i == last:
+            h = _st(h)
             break
         if f"model.{i + 1}.running_mean" in sd:
             j = i + 1
+            h = _st(h)            # the pre-normalisation tensor is stored (statistics pass + apply pass)
             if training:
                 sd[f"model.{j}.num_batches_tracked"] += 1
             h = F.batch_norm(h, sd[f"model.{j}.running_mean"], sd[f"model.{j}.running_var"],
                              sd[f"model.{j}.weight"], sd[f"model.{j}.bias"], training, BN_MOMENTUM, BN_EPS)
-        h = _lrelu(h)
+            h = _st(_lrelu(h))
+        else:                 # (no BatchNorm: conv + bias + LeakyReLU is ONE native store)
+            h = _st(_lrelu(h))
     return h
 
 

@@ -122,11 +122,12 @@ SIGNATURES = {
     "srcgan_bn_eval_rstd": (_I, [_P, _P, _I, _F, _P]),
     "srcgan_bn_apply_lrelu": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
     "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "srcgan_conv1_dgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
     "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
     "srcgan_gn_scratch_floats": (_S, [_I, _I]),
     "srcgan_gn_forward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _L, _I, _I, _F, _I, _F, _I, _P, _P]),
-    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _L, _I, _I, _I, _P, _P]),
+    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
     "srcgan_upsample2_nhwc": (_I, [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_sum2x2_nhwc": (_I, [_P, _I, _P, _I, _P, _I, _F, _I, _I, _I, _I, _I, _P]),
     "srcgan_loss_scratch_floats": (_I, []),

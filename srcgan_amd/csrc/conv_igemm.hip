@@ -316,7 +316,10 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane)) return sg_conv3x3_dma(p, d->dtype, st);
+    // f32 output / residual operands (gradients entering a normalisation backward) are implemented by the generic kernel's epilogue
+    const bool mixed = p.yf32 || p.r1f32;
+    SG_REQUIRE(!(mixed && d->x_plane), "srcgan_conv_igemm: f32 output / residual operands are not available on blocked inputs");
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane) && !mixed) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);

@@ -637,6 +637,64 @@ extern "C" int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const
     return 0;
 }
 
+// --------------------------------------------------------------------------- input gradient of a one-channel convolution, f32
+// PatchGAN's prediction layer (model/model.py:634: Conv2d(8 ndf, 1, 4, 1, 1)).  Its input gradient
+//   g[b,y,x,c] = lrelu'(act[b,y,x,c]) * sum_{ky,kx} dy[b, y+pad-ky, x+pad-kx] * w[0][c][ky][kx]
+// is 16 multiply-adds per element, bound by writing g -- and it enters a BatchNorm backward, whose projection cancels the
+// per-channel common mode of g.  With an lsgan label dy = 2 (pred - t) / N is itself mostly common mode, so both dy and g stay
+// f32 here (a bf16 dy alone made the discriminator's weight gradients ~10 % wrong); weights are the canonical f32 ones.
+// A thread owns 4 channels (their KH*KW taps live in registers) and walks pixels; dy reads are wave-uniform (broadcast).
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void conv1_dgrad_f32_k(const float* __restrict__ dy, const float* __restrict__ w, const T* __restrict__ act,
+                                                         float* __restrict__ g, int H, int W, int OH, int OW, int C, int pad,
+                                                         long npix, float mslope, int ppb) {
+    const int CG = C >> 2, cg = threadIdx.x % CG, pl = threadIdx.x / CG, PL = 256 / CG, c0 = cg * 4;
+    float wr[4][KH * KW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < KH * KW; ++t) wr[i][t] = w[(size_t)(c0 + i) * KH * KW + t];
+    const long p0 = (long)blockIdx.x * ppb, p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    for (long px = p0 + pl; px < p1; px += PL) {
+        const int x = (int)(px % W); const long t = px / W; const int y = (int)(t % H); const long b = t / H;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int oy = y + pad - ky;
+            if ((unsigned)oy >= (unsigned)OH) continue;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int ox = x + pad - kx;
+                if ((unsigned)ox >= (unsigned)OW) continue;
+                const float d = dy[(b * OH + oy) * OW + ox];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = fmaf(d, wr[i][ky * KW + kx], a[i]);
+            }
+        }
+        if (act) {
+            float m[4];
+            load4<T>(act + (size_t)px * C + c0, m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] *= m[i] > 0.f ? 1.f : mslope;
+        }
+        store4<float>(g + (size_t)px * C + c0, a);
+    }
+}
+
+extern "C" int srcgan_conv1_dgrad_f32(const float* dy, const float* w, const void* act, float* g, int B, int H, int W, int OH, int OW,
+                                      int C, int kh, int kw, int pad, float mslope, int dtype, void* stream) {
+    SG_REQUIRE(dy && w && g && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "srcgan_conv1_dgrad_f32: bad arguments");
+    SG_REQUIRE(kh == 4 && kw == 4, "srcgan_conv1_dgrad_f32: 4x4 kernels only (got %dx%d)", kh, kw);
+    SG_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "srcgan_conv1_dgrad_f32: C/4 must divide 256 (C=%d)", C);
+    SG_REQUIRE(OH == H + 2 * pad - kh + 1 && OW == W + 2 * pad - kw + 1, "srcgan_conv1_dgrad_f32: extents do not match a stride-1 convolution");
+    const long npix = (long)B * H * W;
+    const int ppb = 32 * (256 / (C / 4));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_dgrad_f32_k<T, 4, 4>), dim3((unsigned)cdivl(npix, ppb)), dim3(256), 0, (hipStream_t)stream,
+                                             dy, w, (const T*)act, g, H, W, OH, OW, C, pad, npix, mslope, ppb));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
 // --------------------------------------------------------------------------- residual-gradient join
 template <typename T>
 __device__ __forceinline__ size_t ew_chan_off(int c, long plane) {

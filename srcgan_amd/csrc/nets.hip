@@ -43,6 +43,8 @@ struct Conv {
     Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_plane = r.plane; d.r1_cend = cend; d.beta1 = beta; return *this; }
     Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_plane = r.plane; d.r2_cend = cend; d.beta2 = beta; return *this; }
     Conv& lrelu() { d.act = 1; return *this; }
+    Conv& out_f32(bool on = true) { d.y_f32 = on ? 1 : 0; return *this; }       // the output feeds a normalisation backward: keep it f32
+    Conv& res1_f32(bool on = true) { d.r1_f32 = on ? 1 : 0; return *this; }
     Conv& sign_out(void* m) { d.sign_out = m; return *this; }                  // write / read the LeakyReLU sign mask (u32 per pixel)
     Conv& sign_in(const void* m) { d.sign_in = m; return *this; }
     Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
@@ -725,14 +727,21 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     return 0;
 }
 
-struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, gfold, total; };
+struct DBwdPlan { size_t dO, g, dz, dxin, slab, colscr, sums, gfold, total; };
 static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q) {
     const size_t e = P.esz, B = c->B;
     Bump b;
     Q.dO = b.take(B * P.hh[P.L] * P.ww[P.L] * P.out_cs * e);
-    size_t mx = 0;
-    for (int l = 0; l < P.L - 1; ++l) { size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mx) mx = s; }
-    Q.g[0] = b.take(mx); Q.g[1] = b.take(mx);
+    // g: the gradient w.r.t. a layer's output as its consumer's input-gradient convolution leaves it (times LeakyReLU'): f32 when
+    // that layer ends in a BatchNorm (its backward projection cancels most of g: rounded to the compute dtype only afterwards);
+    // dz: the BatchNorm backward's result in the compute dtype, operand of that layer's weight- and input-gradient convolutions.
+    size_t mg = 0, mz = 0;
+    for (int l = 0; l < P.L - 1; ++l) {
+        const bool bn = P.bn_idx[l] >= 0;
+        size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * (bn ? 4 : e); if (s > mg) mg = s;
+        if (bn) { s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mz) mz = s; }
+    }
+    Q.g = b.take(mg); Q.dz = b.take(mz ? mz : 256);
     Q.dxin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);
     Q.gfold = b.take((size_t)P.ch[1] * 32 * 4 * sizeof(float));
     size_t slab = 0;
@@ -860,7 +869,7 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
             }
     }
     SG_TRY(packs.run(P.s2d ? (dx_nchw ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (dx_nchw ? "d_bwd_dx" : "d_bwd"), params[0], st));
-    // ---- dy -> NHWC (1 channel, padded with zeros to 8)
+    // ---- dy -> NHWC (1 channel, padded with zeros to 8): operand of the prediction layer's weight gradient
     const int Lh = P.hh[P.L], Lw = P.ww[P.L];
     TRef dcur = tref(s8 + Q.dO, P.out_cs);
     SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dcur.p, B, 1, Lh, Lw, P.out_cs, dt, st));
@@ -871,13 +880,16 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
         const long npix = (long)B * oh * ow;
         const bool bn = P.bn_idx[l] >= 0;
         if (bn) {
-            // dcur = dL/dy * lrelu'(y) (mask fused in the producer).  BN backward (train): needs sum g, sum g*xhat
+            // g (f32) = dL/dy * lrelu'(y), written by the consumer's input-gradient kernel.  BN backward (train): sum g, sum g*xhat
+            // in f32 from the f32 g, then dz = gamma*rstd*(g - mean g - xhat*mean(g xhat)) rounded ONCE to the compute dtype.
             float* mean = (float*)(w8 + P.stat[l]); float* rstd = mean + 2 * cout;
             TRef z = tref(w8 + P.Z[l], cout);
-            SG_TRY(srcgan_col_reduce(2, dcur.p, dcur.cs, 0, z.p, cout, 0, mean, rstd, npix, cout, 1.f, sums, sums + cout, colscr, dt, st));
+            const void* g32 = s8 + Q.g;
+            SG_TRY(srcgan_col_reduce(3, g32, cout, 0, z.p, cout, 0, mean, rstd, npix, cout, 1.f, sums, sums + cout, colscr, dt, st));
             if (grads[P.pbeta[l]]) SG_HIP(hipMemcpyAsync(grads[P.pbeta[l]], sums, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
             if (grads[P.pg[l]]) SG_HIP(hipMemcpyAsync(grads[P.pg[l]], sums + cout, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-            SG_TRY(srcgan_bn_bwd_apply(dcur.p, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, dt, st));
+            dcur = tref(s8 + Q.dz, cout); dcur_c = cout;
+            SG_TRY(srcgan_bn_bwd_apply(g32, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, 1, dt, st));
         }
         TRef xin_l = l == 0 ? tref(w8 + P.xin, P.s2d ? 32 : P.in_cs) : tref(w8 + P.Y[l - 1], cin);
         if (grads[P.pw[l]]) {
@@ -897,12 +909,16 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
             SG_TRY(srcgan_s2d_to_nchw_f32(dst.p, dx_nchw, B, c->in_ch, c->H, c->W, dt, st));
             return 0;
         }
-        TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g[l & 1], cin);
+        const bool to_bn = l >= 1 && P.bn_idx[l - 1] >= 0;          // the result enters layer l-1's BatchNorm backward: f32
+        TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g, cin);
         if (l == 0) SG_HIP(hipMemsetAsync(dst.p, 0, (size_t)B * ih * iw * P.in_cs * P.esz, (hipStream_t)st));
         TRef mz = l == 0 ? TNULL : tref(w8 + P.Y[l - 1], cin);
-        if (P.st[l] == 1) {
+        if (l == P.L - 1 && to_bn && cin % 4 == 0 && cin / 4 <= 256 && 256 % (cin / 4) == 0) {
+            // prediction layer (one output channel): f32 throughout, straight from the f32 dy autograd handed over
+            SG_TRY(srcgan_conv1_dgrad_f32(dy_nchw, params[P.pw[l]], mz.p, (float*)dst.p, B, ih, iw, oh, ow, cin, 4, 4, 1, 0.2f, dt, st));
+        } else if (P.st[l] == 1) {
             Conv cv(dt, 4, 4, 1);
-            cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, ih, iw, cin).pad(2, 2);
+            cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, ih, iw, cin).pad(2, 2).out_f32(to_bn);
             if (mz.p) cv.mask(mz, 0);
             SG_TRY(cv.run(st));
         } else {
@@ -911,7 +927,7 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
                 const int mh = (ih - a + 1) / 2, mw = (iw - bb + 1) / 2;
                 if (mh <= 0 || mw <= 0) continue;
                 Conv cv(dt, 2, 2, 1);
-                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][q]).out(dst, mh, mw, cin).pad(a ? 0 : 1, bb ? 0 : 1).scatter(2, a, bb, ih, iw);
+                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][q]).out(dst, mh, mw, cin).pad(a ? 0 : 1, bb ? 0 : 1).scatter(2, a, bb, ih, iw).out_f32(to_bn);
                 if (mz.p) cv.mask(mz, 0);
                 SG_TRY(cv.run(st));
             }
@@ -948,6 +964,7 @@ struct RdPlan {
     std::vector<RdT> T; std::vector<RdOp> ops;
     size_t xin, gnfwd, wpk, total, act_bytes;
     std::vector<size_t> g;    // backward: gradient buffer offsets (scratch), same shapes as T
+    std::vector<char> gf32;   // gradient tensor holds f32 elements (it enters a GroupNorm backward) although the compute dtype is narrower
     size_t slab, gnscr, colscr, bwd_total;
 };
 
@@ -1029,9 +1046,13 @@ struct RdBuilder {
         // backward scratch
         Bump s;
         P.g.resize(P.T.size());
+        // The gradient of a GroupNorm OUTPUT enters that GroupNorm's backward projection (g - mean g - xhat mean(g xhat) cancels
+        // most of it): such gradient tensors are f32 whatever the compute dtype, rounded once after the projection.
+        P.gf32.assign(P.T.size(), 0);
+        if (P.esz != 4) for (const RdOp& o : P.ops) if (o.type == 1) P.gf32[o.out] = 1;
         long maxpix = 1;
         for (size_t i = 0; i < P.T.size(); ++i) {
-            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
+            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * (P.gf32[i] ? 4 : P.esz));
             if ((long)B * P.T[i].H * P.T[i].W > maxpix) maxpix = (long)B * P.T[i].H * P.T[i].W;
         }
         size_t slab = 0;
@@ -1212,10 +1233,13 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         const bool need_dx = o.in != 0;
         TRef dx = need_dx ? gt(o.in) : TNULL;
         bool acc = need_dx && written[o.in];
+        const bool dx32 = need_dx && P.gf32[o.in];       // the input's gradient tensor is f32 (it enters a GroupNorm backward)
         if (o.type == 0) {
+            SG_REQUIRE(!P.gf32[o.out], "%s backward: internal error (f32 gradient of a convolution output)", tag);
             if (o.res >= 0) {       // y = conv(x) + res: the residual's gradient is dy itself
                 const RdT tr = P.T[o.res];
                 TRef dr = gt(o.res);
+                SG_REQUIRE(!P.gf32[o.res], "%s backward: a convolution's residual operand produced by a GroupNorm is not supported in bf16", tag);
                 if (!written[o.res]) SG_HIP(hipMemcpyAsync(dr.p, dy.p, (size_t)B * tr.H * tr.W * tr.cs * P.esz, hipMemcpyDeviceToDevice, (hipStream_t)st));
                 else SG_TRY(srcgan_add_inplace(dr.p, tr.cs, 0, dy.p, to.cs, 0, nullptr, 0, 0, 0.f, (long)B * tr.H * tr.W, tr.C, dt, st));
                 written[o.res] = 1;
@@ -1230,23 +1254,23 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
                 SG_REQUIRE(!(acc && ti.act), "%s backward: internal error (activated tensor with two consumers)", tag);
                 if (o.s == 1) {
                     Conv cv(dt, o.k, o.k, 1);
-                    cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad);
-                    if (acc) cv.res1(dx, ti.C, 1.f);
+                    cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad).out_f32(dx32);
+                    if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
                     if (ti.act) { cv.mask(xin, 0); cv.d.mslope = 0.f; }
                     SG_TRY(cv.run(st));
                 } else if (o.k == 1) {
-                    if (!acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * P.esz, (hipStream_t)st));
+                    if (!acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * (dx32 ? 4 : P.esz), (hipStream_t)st));
                     Conv cv(dt, 1, 1, 1);
-                    cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, to.H, to.W, ti.C).pad(0, 0).scatter(2, 0, 0, ti.H, ti.W);
-                    if (acc) cv.res1(dx, ti.C, 1.f);
+                    cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, to.H, to.W, ti.C).pad(0, 0).scatter(2, 0, 0, ti.H, ti.W).out_f32(dx32);
+                    if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
                     SG_TRY(cv.run(st));
                 } else {
                     for (int q = 0; q < 4; ++q) {
                         const int a = q >> 1, bb = q & 1;
                         const int mh = (ti.H - a + 1) / 2, mw = (ti.W - bb + 1) / 2;
                         Conv cv(dt, a ? 2 : 1, bb ? 2 : 1, 1);
-                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(0, 0).scatter(2, a, bb, ti.H, ti.W);
-                        if (acc) cv.res1(dx, ti.C, 1.f);
+                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(0, 0).scatter(2, a, bb, ti.H, ti.W).out_f32(dx32);
+                        if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
                         SG_TRY(cv.run(st));
                     }
                 }
@@ -1260,17 +1284,19 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
             SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (GroupNorm input has two consumers or a fused activation)", tag);
             const int pacc = seen_param[o.w];       // a GroupNorm module applied more than once (edsr.py:41,47,49): gradients add
             seen_param[o.w] = 1;
+            SG_REQUIRE(!dx32, "%s backward: internal error (GroupNorm input produced by a GroupNorm)", tag);
             SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, params[o.w], (const float*)(w8 + o.stats),
-                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
+                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32,
+                                      P.gf32[o.out], o.res >= 0 && P.gf32[o.res], dt, gnscr, st));
             written[o.in] = 1;
         } else if (o.type == 2) {
             if (G(o.w))     // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2
                 SG_TRY(wgrad_call(dt, xin, ti.H, ti.W, ti.C, dy, B, to.H, to.W, to.C, 2, 2, 2, 0, 0, WLayout{(long)to.C * 4, 4, 2, 1, 0}, 1.f, slab, G(o.w), st));
-            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (deconvolution input)", tag);
-            SG_TRY(Conv(dt, 2, 2, 2).in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(0, 0).run(st));
+            SG_REQUIRE(!acc && !ti.act && !P.gf32[o.out], "%s backward: internal error (deconvolution input)", tag);
+            SG_TRY(Conv(dt, 2, 2, 2).in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(0, 0).out_f32(dx32).run(st));
             written[o.in] = 1;
         } else {
-            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (PixelShuffle input)", tag);
+            SG_REQUIRE(!acc && !ti.act && !dx32 && !P.gf32[o.out], "%s backward: internal error (PixelShuffle input)", tag);
             SG_TRY(srcgan_pixel_shuffle_nhwc(dy.p, to.cs, dx.p, ti.cs, B, ti.H, ti.W, to.C, o.k, 1, dt, st));
             written[o.in] = 1;
         }

@@ -88,6 +88,73 @@ def test_rddbnet_full_width_vs_oracle(dt, tol):
     assert worst < tol * 2, worst
 
 
+def _rddbnet_depth_case(dt, hw=64, emulate=False, exact=False):
+    """The generator at the depth the benchmark runs (BASELINE configs[1]: RDDBNet(3,3,4,nb=23), 345 stacked convolutions) on one
+    3 x hw x hw crop against the CPU oracle: output, input gradient and all 697 parameter gradients.  MSE loss: L1's gradient
+    sign(y - t) flips discretely where y ~ t, which says nothing about the kernels.  emulate: the oracle stores activations and
+    conv weights in bf16 like the native perf mode (oracle.storage).  exact: the oracle in float64."""
+    from srcgan_amd import RDDBNet, MSELoss
+    sd = oracle.rddbnet_state(3, 3, 4, 64, 23, 32, seed=7)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(1, 3, hw, hw, generator=g)
+    t = torch.rand(1, 3, 4 * hw, 4 * hw, generator=g)
+
+    def ref(store, dtype=torch.float32):
+        ref_sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().to(dtype).requires_grad_(True)
+        if store:
+            with oracle.storage(torch.bfloat16):
+                yr = oracle.rddbnet_forward(ref_sd, xr, 4)
+        else:
+            yr = oracle.rddbnet_forward(ref_sd, xr, 4)
+        oracle.mse_loss(yr, t.to(dtype)).backward()
+        return yr.detach(), xr.grad, {k: v.grad for k, v in ref_sd.items()}
+
+    net = _load(RDDBNet(3, 3, 4, nf=64, nb=23, gc=32, dtype=dt), sd)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    MSELoss()(y, t.cuda()).backward()
+    grads = {k: p.grad.cpu() for k, p in net.named_parameters()}
+    return (y.detach().cpu(), xg.grad.cpu(), grads), ref(False), (ref(True) if emulate else ref(False, torch.float64) if exact else None)
+
+
+def test_rddbnet_nb23_f32_vs_oracle():
+    """north-star gate (<= 1e-3 relative, fp32) at bench depth.  The output meets it against the f32 oracle directly (observed 7e-6).
+    Gradients: through 345 LeakyReLUs a handful of pre-activations sit within rounding of zero, and the side of zero they land on
+    differs between ANY two f32 evaluation orders -- the reference's own f32 CPU path is 4.6e-3 (max-normalised; 1.8e-3 relative L2)
+    from its float64 evaluation on the input gradient and 7e-4 on a weight gradient (scripts/diag_depth.py).  So the gate is
+    taken against the exact (float64) result: the native error may not exceed max(1e-3, 3 x the f32 oracle's own error)."""
+    (y, dx, g), (yr, dxr, gr), (y64, dx64, g64) = _rddbnet_depth_case("fp32", exact=True)
+    assert rel_err(y, yr) < F32_TOL and rel_err(y, y64) < F32_TOL
+    for err in (rel_err, rel_l2):
+        assert err(dx, dx64) < max(F32_TOL, 3 * err(dxr, dx64)), (err.__name__, err(dx, dx64), err(dxr, dx64))
+        mine, ref = max((err(g[k], g64[k]), k) for k in g), max(err(gr[k], g64[k]) for k in g)
+        assert mine[0] < max(F32_TOL, 3 * ref), (err.__name__, mine, ref)
+    assert max(rel_l2(g[k], g64[k]) for k in g) < F32_TOL
+
+
+def test_rddbnet_nb23_bf16_vs_oracle():
+    """The benchmark's dtype at the benchmark's depth (measured values are printed: pytest -s).  Yardstick: the oracle with bf16
+    STORAGE of activations and conv weights but f32 arithmetic and an exact f32 backward (oracle.storage) -- the best any bf16
+    implementation can do.  Through 345 LeakyReLU layers a 2^-9 storage rounding moves ~1 % of the pre-activations across zero
+    per layer, and the two bf16 evaluations (native, emulated) end up as far from each other as each is from the f32 oracle: at
+    this depth the error is a property of the format, not of an evaluation order.  Measured (hw = 64): output 3.1 % relative L2
+    for both; worst parameter gradient 3.5 % native / 5.7 % emulated; input gradient (through all 345 layers) 28 % both.
+    Gate: the native error against the f32 oracle may not exceed 1.5 x the emulation's own error (+ 0.5 % absolute)."""
+    (y, dx, g), (yr, dxr, gr), (ye, dxe, ge) = _rddbnet_depth_case("bf16", emulate=True)
+    for name, (a, b, c) in (("f32 oracle", (yr, dxr, gr)), ("bf16-storage oracle", (ye, dxe, ge))):
+        errs = sorted(((rel_l2(g[k], c[k]), k) for k in g), reverse=True)
+        print(f"nb=23 bf16 vs {name}: y {rel_l2(y, a):.4f} dx {rel_l2(dx, b):.4f} worst grads {errs[:3]} median {errs[len(errs) // 2][0]:.4f}")
+    fmt = sorted(((rel_l2(ge[k], gr[k]), k) for k in g), reverse=True)
+    print(f"   format alone (bf16-storage oracle vs f32 oracle): y {rel_l2(ye, yr):.4f} dx {rel_l2(dxe, dxr):.4f} worst {fmt[:2]} median {fmt[len(fmt) // 2][0]:.4f}")
+    bound = lambda e: 1.5 * e + 5e-3
+    assert rel_l2(y, yr) < bound(rel_l2(ye, yr)) and rel_l2(y, yr) < 6e-2
+    assert rel_l2(dx, dxr) < bound(rel_l2(dxe, dxr))
+    assert max(rel_l2(g[k], gr[k]) for k in g) < bound(fmt[0][0])
+    med = sorted(rel_l2(g[k], gr[k]) for k in g)[len(g) // 2]
+    assert med < bound(fmt[len(fmt) // 2][0]) and med < 3e-2
+
+
 @pytest.mark.parametrize("tag", ["nlayerd_3", "nlayerd_2"])
 def test_nlayerd_golden_f32(tag):
     from srcgan_amd import NLayerDiscriminator, GANLoss
@@ -115,29 +182,52 @@ def test_nlayerd_golden_f32(tag):
 
 
 @pytest.mark.parametrize("hw", [(96, 128), (97, 128)])
-@pytest.mark.parametrize("dt,tol", [("fp32", F32_TOL), ("bf16", 8e-2)])
-def test_nlayerd_full_width_vs_oracle(dt, tol, hw):
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_nlayerd_full_width_vs_oracle(dt, hw):
     """ndf=64, 3 layers (3->64->128->256->512->1) on a 3x96x128 batch (first layer in its space-to-depth form) and on an odd
     height (plain 4x4 s2 form), incl. a frozen pass (dgrad only).
-    bf16 bound is loose on purpose: with a constant lsgan label the incoming gradient is nearly uniform per channel,
-    so BatchNorm backward (g - mean g - xhat * mean(g xhat)) cancels most of a bf16-rounded g (f32 mode: 4e-6)."""
+    fp32: <= 1e-3 on everything.  bf16: two references.  Against the oracle that merely STORES activations and conv weights in
+    bf16 (f32 arithmetic, f32 backward; oracle.storage) every gradient is within 3 % relative L2 (measured 1.3-2.6 %): that is what
+    the kernels add; and no gradient is further from the f32 oracle than 1.5 x that emulation is itself (+ 0.5 %).
+    Against the pure-f32 oracle the output is within 1.5 % and the gradients within ~10 %: with a constant lsgan label the
+    incoming gradient is nearly uniform per channel and each BatchNorm backward (g - mean g - xhat * mean(g xhat)) cancels most
+    of it, so the 1 % the bf16 forward moves the prediction by is amplified ~10x -- the bf16-storage oracle, whose backward is
+    exact, shows the same 6-10 % (scripts/diag_d_bf16.py prints both).  The gradient entering each BatchNorm backward is kept
+    in f32 (srcgan_conv_desc.y_f32, srcgan_conv1_dgrad_f32) and rounded to bf16 once, after the projection."""
     from srcgan_amd import NLayerDiscriminator, GANLoss
     sd = oracle.nlayer_d_state(3, 64, 3, seed=5)
     net = _load(NLayerDiscriminator(3, 64, 3, dtype=dt), sd)
     torch.manual_seed(1)
     x = torch.rand(2, 3, *hw)
-    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
-    xr = x.clone().requires_grad_(True)
-    yr = oracle.nlayer_d_forward(ref_sd, xr, True)
-    oracle.gan_loss(yr, False).backward()
+
+    def ref(store):
+        ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        if store:
+            with oracle.storage(torch.bfloat16):
+                yr = oracle.nlayer_d_forward(ref_sd, xr, True)
+        else:
+            yr = oracle.nlayer_d_forward(ref_sd, xr, True)
+        oracle.gan_loss(yr, False).backward()
+        return yr.detach(), xr.grad, ref_sd
+
     xg = x.cuda().requires_grad_(True)
     y = net(xg)
     GANLoss("lsgan", device="cuda")(y, False).backward()
-    err = rel_err if dt == "fp32" else rel_l2     # bf16: relative L2 (8-bit mantissa noise per element)
-    assert err(y.cpu(), yr) < tol
-    assert err(xg.grad.cpu(), xr.grad) < tol * 2
-    worst = max(err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
-    assert worst < tol * 2, worst
+    yr, dxr, ref_sd = ref(False)
+    if dt == "fp32":
+        assert rel_err(y.cpu(), yr) < F32_TOL
+        assert rel_err(xg.grad.cpu(), dxr) < F32_TOL * 2
+        worst = max(rel_err(p.grad.cpu(), ref_sd[k].grad) for k, p in net.named_parameters())
+        assert worst < F32_TOL * 2, worst
+    else:
+        ye, dxe, emu_sd = ref(True)
+        bound = lambda e: 1.5 * e + 5e-3           # yardstick: the bf16-storage oracle's own distance from the f32 oracle
+        assert rel_l2(y.cpu(), ye) < 5e-3 and rel_l2(y.cpu(), yr) < 1.5e-2
+        assert rel_l2(xg.grad.cpu(), dxe) < 3e-2 and rel_l2(xg.grad.cpu(), dxr) < bound(rel_l2(dxe, dxr))
+        for k, p in net.named_parameters():
+            e_emu, e_f32, fmt = rel_l2(p.grad.cpu(), emu_sd[k].grad), rel_l2(p.grad.cpu(), ref_sd[k].grad), rel_l2(emu_sd[k].grad, ref_sd[k].grad)
+            assert e_emu < 3e-2 and e_f32 < bound(fmt), (k, e_emu, e_f32, fmt)
     # frozen discriminator (train.py:330): no parameter grads, input grad still flows
     for p in net.parameters():
         p.requires_grad_(False)
@@ -276,26 +366,42 @@ def test_resdeconv_golden_f32(tag):
 
 
 def test_resdeconv_bf16_vs_oracle():
-    """bf16 perf mode of the colouriser (fp32 mode is the parity gate, above).  Forward within 5 % relative L2; the gradients
-    of the last decoder stage within 5 %; deeper gradients are compared by direction only: each of the 20 GroupNorm
-    backward passes projects the common-mode part of the incoming gradient out, so bf16's 2^-9 rounding of a gradient is
-    amplified relative to what survives (measured on this random-initialised case: 0.3 % at pred.weight, 33 % at layer4,
-    55 % at layer1 in relative L2 -- cosine similarity >= 0.8 everywhere)."""
+    """bf16 perf mode of the colouriser (fp32 mode is the parity gate, above).  Yardstick: the oracle that STORES activations and conv
+    weights in bf16 with f32 arithmetic and an exact f32 backward (oracle.storage) -- the best any bf16 implementation can do.  On
+    this random-initialised case that emulation is itself 30-55 % (relative L2) from the f32 oracle on the gradients of
+    layer1..layer4: each of the 20 GroupNorm backward passes projects the common-mode part of its incoming gradient out, so a 2^-9
+    perturbation of a forward activation is amplified relative to what survives.  It is a property of the format, not of the
+    kernels (round 1 read it as one).  Gate: no native gradient is further from the f32 oracle than 1.5 x the emulation is
+    (+ 0.5 %); output and last decoder stage within 5 %.  The gradient entering each GroupNorm backward stays f32 until after the
+    projection (srcgan_gn_backward dy_f32), so the backward adds no cancellation error of its own."""
     from srcgan_amd import ResDeconv, MSELoss
     torch.manual_seed(3)
     net = ResDeconv(1, 3, dtype="bf16").cuda()
-    sd = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in net.named_parameters()}
     x, t = torch.rand(2, 1, 64, 48), torch.rand(2, 3, 64, 48)
-    yr = oracle.resdeconv_forward(sd, x)
-    oracle.mse_loss(yr, t).backward()
+
+    def ref(store):
+        sd = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in net.named_parameters()}
+        if store:
+            with oracle.storage(torch.bfloat16):
+                yr = oracle.resdeconv_forward(sd, x)
+        else:
+            yr = oracle.resdeconv_forward(sd, x)
+        oracle.mse_loss(yr, t).backward()
+        return yr.detach(), sd
+
+    (yr, sd), (ye, se) = ref(False), ref(True)
     y = net(x.cuda())
     MSELoss()(y, t.cuda()).backward()
-    assert rel_l2(y.cpu(), yr) < 5e-2
-    cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
-    for k, p in net.named_parameters():
+    bound = lambda e: 1.5 * e + 5e-3
+    assert rel_l2(y.cpu(), yr) < 5e-2 and rel_l2(y.cpu(), yr) < bound(rel_l2(ye, yr))
+    rows = [(k, rel_l2(p.grad.cpu(), sd[k].grad), rel_l2(se[k].grad, sd[k].grad), rel_l2(p.grad.cpu(), se[k].grad)) for k, p in net.named_parameters()]
+    worst = sorted(rows, key=lambda r: -r[1])[:3]
+    print("ResDeconv bf16 (name, native vs f32, bf16-storage oracle vs f32, native vs bf16-storage oracle): worst", worst,
+          "median native-vs-f32", sorted(r[1] for r in rows)[len(rows) // 2])
+    for k, e_f32, fmt, e_emu in rows:
+        assert e_f32 < bound(fmt), (k, e_f32, fmt)
         if k.startswith(("pred", "deconv13", "upRes3.1")):
-            assert rel_l2(p.grad.cpu(), sd[k].grad) < 5e-2, k
-        assert cos(p.grad.cpu(), sd[k].grad) > 0.75, (k, cos(p.grad.cpu(), sd[k].grad))
+            assert e_f32 < 5e-2, k
 
 
 @pytest.mark.parametrize("tag", ["espcn_x2", "espcn_x3", "srcnn", "edsr_x2", "edsr_x4"])
