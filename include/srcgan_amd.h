@@ -103,11 +103,6 @@ typedef struct srcgan_conv_desc {
      *   sign_in : read instead of mz:  v *= bit ? 1 : mslope
      * A descriptor that sets either and does not meet the conditions is refused (no silent fallback). */
     void* sign_out; const void* sign_in;
-    /* y_f32: the output tensor is f32 whatever `dtype` says (y_cs still counts elements).  Set on the input-gradient convolutions
-     * whose result enters a BatchNorm / GroupNorm backward projection: g - mean(g) - xhat*mean(g*xhat) cancels most of g, so g is
-     * rounded to the compute dtype only after it.  r1_f32: the r1 residual operand is f32 likewise.  Kernels that do not
-     * implement a requested combination refuse the descriptor. */
-    int y_f32, r1_f32;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 
@@ -164,8 +159,6 @@ int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream);
  *   mode 0: out0[c] = scale * sum a[p,c]                         (bias grad; BN mean)
  *   mode 1: out0[c] = scale * sum (a[p,c]-m[c])^2                (BN variance)
  *   mode 2: out0[c] = sum g[p,c] ; out1[c] = sum g[p,c]*(z[p,c]-m[c])*rstd[c]   (BN backward)
- *   mode 3: mode 2 with g stored as f32 whatever `dtype` says (z stays dtype): the gradient entering a BatchNorm backward
- *           of a bf16 network is kept in f32 until after the projection (most of it is common-mode and cancels there)
  * scratch: 2*nblk*C floats, nblk = srcgan_col_reduce_blocks(npix).
  * ------------------------------------------------------------------------- */
 int srcgan_col_reduce_blocks(long npix);
@@ -185,14 +178,7 @@ int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, const float
                           const float* beta, long npix, int C, int cs, float slope, int dtype, void* stream);
 int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mean, const float* rstd,
                         const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
-                        int g_f32, int dtype, void* stream);      /* g_f32: g is f32 whatever dtype says (then dz != g) */
-
-/* Input gradient of a ONE-output-channel stride-1 convolution (PatchGAN's prediction layer, model/model.py:634), all f32:
- *   g[b,y,x,c] = (act ? (act[b,y,x,c] > 0 ? 1 : mslope) : 1) * sum_{ky,kx} dy[b, y+pad-ky, x+pad-kx] * w[0][c][ky][kx]
- * dy: f32 [B][OH][OW] (the NCHW gradient as autograd hands it over), w: canonical f32 [1][C][kh][kw], act: NHWC activation of
- * `dtype` (dense, cs == C) or null, g: f32 NHWC [B][H][W][C].  4x4 kernels; C/4 must divide 256. */
-int srcgan_conv1_dgrad_f32(const float* dy, const float* w, const void* act, float* g, int B, int H, int W, int OH, int OW,
-                           int C, int kh, int kw, int pad, float mslope, int dtype, void* stream);
+                        int dtype, void* stream);
 
 /* y[p, ycoff+c] = (y + x[p, xcoff+c]) * (mz ? (mz[p, mzcoff+c] > 0 ? 1 : mslope) : 1) for c < C
  * (residual gradient joins; optional LeakyReLU' of the tensor the gradient belongs to) */
@@ -215,9 +201,7 @@ int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void
                       float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream);
 int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
                        void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
-                       float slope, int B, long hw, int C, int G, int dy_f32, int dres_f32, int dtype, float* scratch, void* stream);
-/* dy_f32 / dres_f32: dy / dres hold f32 elements whatever dtype says (their channel strides still count elements): the gradient
- * entering a normalisation backward is rounded to the compute dtype only after the projection. */
+                       float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream);
 
 /* x2 nearest up-sampling of an NHWC feature map (src may be a channel slice of a blocked buffer: s_plane != 0) and its
  * adjoint: dst[y][x] = sum of the 2x2 block of src, times LeakyReLU'(mz[y][x]) when mz is given.  Replaces
@@ -271,6 +255,23 @@ typedef struct srcgan_rddbnet_cfg {
                           is never applied: pass it, it gets no gradient); `up` = 1, `nb` = RRDBs per stack.
                           params/grads follow the respective state_dict order. */
 } srcgan_rddbnet_cfg;
+/* Per-call options of the whole-network entry points (the plain forms pass NULL):
+ *   wpack / pack    persistent packed-weight buffer (srcgan_*_wpack_bytes(cfg), 256-byte aligned).  NULL: the weights are packed
+ *                   into the call's workspace every call.  Given: packed into it only when pack != 0, so a caller that tracks
+ *                   weight updates packs ONCE per optimiser step although a cycle step runs each generator three times
+ *                   (train.py:228-260).  Forward and backward packs are separate regions: pack the forward set in a forward
+ *                   call, the backward set in a backward call.  The layout depends on the cfg's channel counts, dtype, up /
+ *                   down / legacy (and for the discriminator on H, W parity), not on B, H, W.
+ *   rrdb_lo/rrdb_hi rddbnet backward only.  hi <= 0: the whole backward.  Otherwise this call handles the RRDBs [lo, hi), last
+ *                   to first; the call with hi == number of RRDBs also runs everything behind the trunk (conv_last, up-sampler,
+ *                   trunk_conv), the call with lo == 0 everything in front of it (conv_first, dx).  Calls come in descending,
+ *                   gap-free order on one stream with the same ws / scratch / grads; when a call returns, the gradients of the
+ *                   parameters it covers are final (data parallel: their all-reduce starts while earlier blocks still compute). */
+typedef struct srcgan_net_opts {
+    void* wpack;
+    int pack;
+    int rrdb_lo, rrdb_hi;
+} srcgan_net_opts;
 int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);
 size_t srcgan_rddbnet_ws_bytes(const srcgan_rddbnet_cfg* c);        /* forward workspace (kept for backward) */
 size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c);
@@ -279,6 +280,11 @@ int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* x_nchw, con
 /* grads[i] may be NULL (parameter frozen); dx_nchw may be NULL */
 int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
                             void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
+size_t srcgan_rddbnet_wpack_bytes(const srcgan_rddbnet_cfg* c);
+int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
+                              void* ws, float* y_nchw, const srcgan_net_opts* opt, void* stream);
+int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
+                               void* ws, void* scratch, float* const* grads, float* dx_nchw, const srcgan_net_opts* opt, void* stream);
 
 /* NLayerDiscriminator (model/model.py:595-639).  params in state_dict order of the
  * learnable tensors: conv0.w, conv0.b, [conv_l.w, bn_l.gamma, bn_l.beta]*, conv_last.w, conv_last.b.
@@ -297,6 +303,12 @@ int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, con
                            float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw, void* stream);
 int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
                             void* ws, void* scratch, float* const* grads, float* dx_nchw, void* stream);
+size_t srcgan_nlayerd_wpack_bytes(const srcgan_nlayerd_cfg* c);
+int srcgan_nlayerd_forward_ex(const srcgan_nlayerd_cfg* c, const float* x_nchw, const float* const* params,
+                              float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw,
+                              const srcgan_net_opts* opt, void* stream);
+int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
+                               void* ws, void* scratch, float* const* grads, float* dx_nchw, const srcgan_net_opts* opt, void* stream);
 
 /* ResDeconv colouriser (resdeconv.py:99-195; C network of trainCas.py:31,99-100): [B,3,H,W] f32 NCHW -> [B,tar_ch,H,W];
  * H, W multiples of 16.  params/grads in state_dict order (conv1.weight, bn1.{weight,bias}, layer1.0.conv1.weight, ...,

@@ -55,7 +55,7 @@ class ConvDesc(C.Structure):
                 ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("slope", C.c_float), ("mslope", C.c_float),
                 ("act", C.c_int),
                 ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long), ("rev_batch", C.c_int),
-                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p), ("y_f32", C.c_int), ("r1_f32", C.c_int)]
+                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -83,6 +83,10 @@ class WgradDenseDesc(C.Structure):
 class RddbCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("up", C.c_int), ("nf", C.c_int), ("nb", C.c_int), ("gc", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("down", C.c_int), ("legacy", C.c_int)]
+
+
+class NetOpts(C.Structure):
+    _fields_ = [("wpack", C.c_void_p), ("pack", C.c_int), ("rrdb_lo", C.c_int), ("rrdb_hi", C.c_int)]
 
 
 class ResDeconvCfg(C.Structure):
@@ -121,13 +125,12 @@ SIGNATURES = {
     "srcgan_bn_finalize": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _P]),
     "srcgan_bn_eval_rstd": (_I, [_P, _P, _I, _F, _P]),
     "srcgan_bn_apply_lrelu": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
-    "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
-    "srcgan_conv1_dgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "srcgan_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "srcgan_add_inplace": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _F, _L, _I, _I, _P]),
     "srcgan_add_inplace_planes": (_I, [_P, _I, _I, _L, _P, _I, _I, _L, _P, _I, _I, _L, _F, _L, _I, _I, _P]),
     "srcgan_gn_scratch_floats": (_S, [_I, _I]),
     "srcgan_gn_forward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _L, _I, _I, _F, _I, _F, _I, _P, _P]),
-    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "srcgan_gn_backward": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _L, _I, _I, _I, _P, _P]),
     "srcgan_upsample2_nhwc": (_I, [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_sum2x2_nhwc": (_I, [_P, _I, _P, _I, _P, _I, _F, _I, _I, _I, _I, _I, _P]),
     "srcgan_loss_scratch_floats": (_I, []),
@@ -167,6 +170,12 @@ SIGNATURES = {
     "srcgan_rddbnet_bwd_scratch_bytes": (_S, [C.POINTER(RddbCfg)]),
     "srcgan_rddbnet_forward": (_I, [C.POINTER(RddbCfg), _P, _P, _P, _P, _P]),
     "srcgan_rddbnet_backward": (_I, [C.POINTER(RddbCfg), _P, _P, _P, _P, _P, _P, _P]),
+    "srcgan_rddbnet_wpack_bytes": (_S, [C.POINTER(RddbCfg)]),
+    "srcgan_rddbnet_forward_ex": (_I, [C.POINTER(RddbCfg), _P, _P, _P, _P, C.POINTER(NetOpts), _P]),
+    "srcgan_rddbnet_backward_ex": (_I, [C.POINTER(RddbCfg), _P, _P, _P, _P, _P, _P, C.POINTER(NetOpts), _P]),
+    "srcgan_nlayerd_wpack_bytes": (_S, [C.POINTER(NLayerDCfg)]),
+    "srcgan_nlayerd_forward_ex": (_I, [C.POINTER(NLayerDCfg), _P, _P, _P, _P, _P, _P, C.POINTER(NetOpts), _P]),
+    "srcgan_nlayerd_backward_ex": (_I, [C.POINTER(NLayerDCfg), _P, _P, _P, _P, _P, _P, C.POINTER(NetOpts), _P]),
     "srcgan_nlayerd_num_params": (_I, [C.POINTER(NLayerDCfg)]),
     "srcgan_nlayerd_out_hw": (_I, [C.POINTER(NLayerDCfg), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "srcgan_nlayerd_ws_bytes": (_S, [C.POINTER(NLayerDCfg)]),

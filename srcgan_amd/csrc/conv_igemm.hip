@@ -287,10 +287,8 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.r2coff = d->r2_coff; p.r2cend = d->r2_cend;
     p.mzcoff = d->mz_coff; p.mzc0 = d->mz_c0;
     auto pl = [](long v) { return v ? v : 64L; };      // plane stride 0 = interleaved NHWC
-    p.yf32 = d->y_f32 != 0 && esz != 4; p.r1f32 = d->r1_f32 != 0 && esz != 4;
-    SG_REQUIRE(!(p.yf32 || p.r1f32) || (!d->y_plane && !d->r1_plane), "srcgan_conv_igemm: f32 output / residual operands are interleaved NHWC only");
-    p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * (p.yf32 ? 4 : esz); p.yplane = pl(d->y_plane);
-    p.r1pix = (long)d->r1_cs * (p.r1f32 ? 4 : esz); p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
+    p.xpix = (long)d->x_cs * esz; p.xplane = pl(d->x_plane); p.ypix = (long)d->y_cs * esz; p.yplane = pl(d->y_plane);
+    p.r1pix = (long)d->r1_cs * esz; p.r1plane = pl(d->r1_plane); p.r2pix = (long)d->r2_cs * esz; p.r2plane = pl(d->r2_plane);
     p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
     p.rev = d->rev_batch;
     p.sgn_out = (unsigned char*)d->sign_out; p.sgn_in = (const unsigned char*)d->sign_in;
@@ -316,10 +314,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
     }
     hipStream_t st = (hipStream_t)stream;
-    // f32 output / residual operands (gradients entering a normalisation backward) are implemented by the generic kernel's epilogue
-    const bool mixed = p.yf32 || p.r1f32;
-    SG_REQUIRE(!(mixed && d->x_plane), "srcgan_conv_igemm: f32 output / residual operands are not available on blocked inputs");
-    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane) && !mixed) return sg_conv3x3_dma(p, d->dtype, st);
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane)) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);

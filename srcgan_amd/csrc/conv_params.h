@@ -18,7 +18,6 @@ struct ConvP {
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
     int rev;      // images are walked last to first
-    int yf32, r1f32;   // y / r1 hold f32 elements whatever T is (gradients entering a normalisation backward): ypix / r1pix are in f32 bytes
     unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
@@ -63,9 +62,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                         for (int i = 0; i < 4; ++i) v[i] += bv[i]; }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
-                    if (r1p && co0 < p.r1cend) { float rv[4];
-                        if (p.r1f32) load4<float>((const float*)(r1p + chan_off<float>(p.r1coff + co0, p.r1plane)), rv);
-                        else load4<T>((const T*)(r1p + chan_off<T>(p.r1coff + co0, p.r1plane)), rv);
+                    if (r1p && co0 < p.r1cend) { float rv[4]; load4<T>((const T*)(r1p + chan_off<T>(p.r1coff + co0, p.r1plane)), rv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += p.beta1 * rv[i]; }
                     if (r2p && co0 < p.r2cend) { float rv[4]; load4<T>((const T*)(r2p + chan_off<T>(p.r2coff + co0, p.r2plane)), rv);
@@ -77,8 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                     if (mzp && co0 >= p.mzc0) { float zv[4]; load4<T>((const T*)(mzp + chan_off<T>(p.mzcoff + co0, p.mzplane)), zv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] *= (zv[i] > 0.f ? 1.f : p.mslope); }
-                    if (p.yf32) store4<float>((float*)(yp + chan_off<float>(p.ycoff + co0, p.yplane)), v);
-                    else store4<T>((T*)(yp + chan_off<T>(p.ycoff + co0, p.yplane)), v);
+                    store4<T>((T*)(yp + chan_off<T>(p.ycoff + co0, p.yplane)), v);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -87,13 +83,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                         float u = v[i];
                         if (p.bias) u += p.bias[co];
                         u *= p.alpha;
-                        if (r1p && co < p.r1cend) u += p.beta1 * (p.r1f32 ? *(const float*)(r1p + chan_off<float>(p.r1coff + co, p.r1plane))
-                                                                          : to_f(*(const T*)(r1p + chan_off<T>(p.r1coff + co, p.r1plane))));
+                        if (r1p && co < p.r1cend) u += p.beta1 * to_f(*(const T*)(r1p + chan_off<T>(p.r1coff + co, p.r1plane)));
                         if (r2p && co < p.r2cend) u += p.beta2 * to_f(*(const T*)(r2p + chan_off<T>(p.r2coff + co, p.r2plane)));
                         if (p.act) u = u > 0.f ? u : u * p.slope;
                         if (mzp && co >= p.mzc0) u *= (to_f(*(const T*)(mzp + chan_off<T>(p.mzcoff + co, p.mzplane))) > 0.f ? 1.f : p.mslope);
-                        if (p.yf32) *(float*)(yp + chan_off<float>(p.ycoff + co, p.yplane)) = u;
-                        else *(T*)(yp + chan_off<T>(p.ycoff + co, p.yplane)) = from_f<T>(u);
+                        *(T*)(yp + chan_off<T>(p.ycoff + co, p.yplane)) = from_f<T>(u);
                     }
                 }
             }

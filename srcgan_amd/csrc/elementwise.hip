@@ -378,8 +378,8 @@ extern "C" int srcgan_pack_weight(const float* w, void* wp, int rows, int kdim, 
 // --------------------------------------------------------------------------- column reductions
 // Block = 64 channel lanes x 4 pixel lanes.  Stage 1 writes partial[which][blk][c]; stage 2 sums
 // the blocks in index order.
-template <typename T, int MODE, typename TA = T>
-__global__ __launch_bounds__(256) void col_reduce_k(const TA* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_k(const T* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
                                                     int zCs, int zcoff, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, long npix, int C,
                                                     float* __restrict__ partial) {
@@ -413,14 +413,13 @@ __global__ __launch_bounds__(256) void col_reduce_k(const TA* __restrict__ a, in
 
 // Vectorised variant (C % EPP == 0, (C/EPP) | 256): a thread owns EPP consecutive channels (one 16-byte load per
 // pixel) and every 256/(C/EPP)-th pixel, so a wave reads whole contiguous pixel records.
-template <typename T, int MODE, typename TA = T>
-__global__ __launch_bounds__(256) void col_reduce_vec_k(const TA* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_vec_k(const T* __restrict__ a, int aCs, int acoff, const T* __restrict__ z,
                                                         int zCs, int zcoff, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, long npix, int C,
                                                         float* __restrict__ partial) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
-    typedef __attribute__((ext_vector_type(EPP))) TA vecA;      // TA = float beside T = bf16: the f32 gradient of a bf16 network
     __shared__ float red[2][256 * EPP];
     const int G = C / EPP, PL = 256 / G;
     const int cg = threadIdx.x % G, pl = threadIdx.x / G, c0 = cg * EPP;
@@ -430,7 +429,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_k(const TA* __restrict__ a
 #pragma unroll
     for (int i = 0; i < EPP; ++i) { s0[i] = 0.f; s1[i] = 0.f; mu[i] = MODE >= 1 ? mean[c0 + i] : 0.f; rs[i] = MODE == 2 ? rstd[c0 + i] : 0.f; }
     for (long px = p0 + pl; px < p1; px += PL) {
-        const vecA av = *(const vecA*)(a + (size_t)px * aCs + acoff + c0);
+        const vecT av = *(const vecT*)(a + (size_t)px * aCs + acoff + c0);
         if (MODE == 2) {
             const vecT zv = *(const vecT*)(z + (size_t)px * zCs + zcoff + c0);
 #pragma unroll
@@ -491,22 +490,15 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
                                  const float* m, const float* rstd, long npix, int C, float scale,
                                  float* out0, float* out1, float* scratch, int dtype, void* stream) {
     SG_REQUIRE(a && out0 && scratch && npix > 0 && C > 0, "srcgan_col_reduce: bad arguments");
-    SG_REQUIRE(mode >= 0 && mode <= 3, "srcgan_col_reduce: bad mode %d", mode);
+    SG_REQUIRE(mode >= 0 && mode <= 2, "srcgan_col_reduce: bad mode %d", mode);
     SG_REQUIRE(mode == 0 || m, "srcgan_col_reduce: mode %d needs mean", mode);
-    SG_REQUIRE(mode < 2 || (z && rstd && out1), "srcgan_col_reduce: mode 2/3 needs z, rstd, out1");
+    SG_REQUIRE(mode != 2 || (z && rstd && out1), "srcgan_col_reduce: mode 2 needs z, rstd, out1");
     const int nblk = srcgan_col_reduce_blocks(npix);
     hipStream_t st = (hipStream_t)stream;
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
-    const bool a32 = mode == 3 && dtype != SRCGAN_F32;          // mode 3 = mode 2 with `a` in f32 whatever the dtype
-    if (mode == 3) mode = 2;
-    const int aal = a32 ? 32 : 16;
-    const bool vec = C % epp == 0 && 256 % (C / epp) == 0 && a_cs % epp == 0 && a_coff % epp == 0 && ((uintptr_t)a % aal) == 0 &&
+    const bool vec = C % epp == 0 && 256 % (C / epp) == 0 && a_cs % epp == 0 && a_coff % epp == 0 && ((uintptr_t)a % 16) == 0 &&
                      (mode != 2 || (z_cs % epp == 0 && z_coff % epp == 0 && ((uintptr_t)z % 16) == 0));
-    if (a32) {
-        using T = __bf16;
-        if (vec) hipLaunchKernelGGL((col_reduce_vec_k<T, 2, float>), dim3(nblk), dim3(256), 0, st, (const float*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
-        else hipLaunchKernelGGL((col_reduce_k<T, 2, float>), dim3(nblk), dim3(256), 0, st, (const float*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
-    } else if (vec) {
+    if (vec) {
         DISPATCH_DTYPE(dtype, {
             if (mode == 0) hipLaunchKernelGGL((col_reduce_vec_k<T, 0>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
             else if (mode == 1) hipLaunchKernelGGL((col_reduce_vec_k<T, 1>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
@@ -519,7 +511,7 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
         else hipLaunchKernelGGL((col_reduce_k<T, 2>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);
     });
     SG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode >= 2 ? out1 : nullptr);
+    hipLaunchKernelGGL(col_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, st, scratch, nblk, C, scale, out0, mode == 2 ? out1 : nullptr);
     SG_LAUNCH_CHECK();
     return 0;
 }
@@ -578,8 +570,8 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ z, T* __
     }
 }
 
-template <typename T, typename TG = T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_k(const TG* __restrict__ g, const T* __restrict__ z, T* __restrict__ dz,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* __restrict__ g, const T* __restrict__ z, T* __restrict__ dz,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, long npix, int C, float invn) {
@@ -587,7 +579,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const TG* __restrict__ g, 
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
     const int G = C / EPP, PL = 256 / G;
     const int c0 = (threadIdx.x % G) * EPP, pl = threadIdx.x / G;
-    typedef __attribute__((ext_vector_type(EPP))) TG vecG;
     float ka[EPP], kb[EPP], kc[EPP], mu[EPP];          // dz = ka * (g - kb - (z - mu) * kc)
 #pragma unroll
     for (int i = 0; i < EPP; ++i) {
@@ -595,7 +586,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const TG* __restrict__ g, 
         kc[i] = rstd[c0 + i] * sum_gx[c0 + i] * invn; mu[i] = mean[c0 + i];
     }
     for (long px = (long)blockIdx.x * PL + pl; px < npix; px += (long)gridDim.x * PL) {
-        const vecG gv = *(const vecG*)(g + (size_t)px * C + c0);
+        const vecT gv = *(const vecT*)(g + (size_t)px * C + c0);
         const vecT zv = *(const vecT*)(z + (size_t)px * C + c0);
         vecT o;
 #pragma unroll
@@ -619,78 +610,15 @@ extern "C" int srcgan_bn_apply_lrelu(const void* z, void* y, const float* mean, 
 
 extern "C" int srcgan_bn_bwd_apply(const void* g, const void* z, void* dz, const float* mean, const float* rstd,
                                    const float* gamma, const float* sum_g, const float* sum_gx, long npix, int C, int cs,
-                                   int g_f32, int dtype, void* stream) {
+                                   int dtype, void* stream) {
     SG_REQUIRE(g && z && dz && mean && rstd && gamma && sum_g && sum_gx && npix > 0, "srcgan_bn_bwd_apply: bad arguments");
-    SG_REQUIRE(!(g_f32 && dtype != SRCGAN_F32 && (const void*)g == (const void*)dz), "srcgan_bn_bwd_apply: an f32 gradient cannot be overwritten in place by a 2-byte dz");
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(cs == C && C % epp == 0 && 256 % (C / epp) == 0,
                "srcgan_bn_bwd_apply: needs a dense NHWC tensor with C a multiple of %d and C/%d dividing 256", epp, epp);
     const int pl = 256 / (C / epp);
-    if (g_f32 && dtype == SRCGAN_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_k<__bf16, float>), dim3(ew_blocks(npix, pl * 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)g, (const __bf16*)z, (__bf16*)dz, mean, rstd, gamma, sum_g, sum_gx, npix, C, 1.f / (float)npix);
-    else
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_blocks(npix, pl * 4)), dim3(256), 0, (hipStream_t)stream,
                                              (const T*)g, (const T*)z, (T*)dz, mean, rstd, gamma, sum_g, sum_gx, npix, C,
                                              1.f / (float)npix));
-    SG_LAUNCH_CHECK();
-    return 0;
-}
-
-// --------------------------------------------------------------------------- input gradient of a one-channel convolution, f32
-// PatchGAN's prediction layer (model/model.py:634: Conv2d(8 ndf, 1, 4, 1, 1)).  Its input gradient
-//   g[b,y,x,c] = lrelu'(act[b,y,x,c]) * sum_{ky,kx} dy[b, y+pad-ky, x+pad-kx] * w[0][c][ky][kx]
-// is 16 multiply-adds per element, bound by writing g -- and it enters a BatchNorm backward, whose projection cancels the
-// per-channel common mode of g.  With an lsgan label dy = 2 (pred - t) / N is itself mostly common mode, so both dy and g stay
-// f32 here (a bf16 dy alone made the discriminator's weight gradients ~10 % wrong); weights are the canonical f32 ones.
-// A thread owns 4 channels (their KH*KW taps live in registers) and walks pixels; dy reads are wave-uniform (broadcast).
-template <typename T, int KH, int KW>
-__global__ __launch_bounds__(256) void conv1_dgrad_f32_k(const float* __restrict__ dy, const float* __restrict__ w, const T* __restrict__ act,
-                                                         float* __restrict__ g, int H, int W, int OH, int OW, int C, int pad,
-                                                         long npix, float mslope, int ppb) {
-    const int CG = C >> 2, cg = threadIdx.x % CG, pl = threadIdx.x / CG, PL = 256 / CG, c0 = cg * 4;
-    float wr[4][KH * KW];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < KH * KW; ++t) wr[i][t] = w[(size_t)(c0 + i) * KH * KW + t];
-    const long p0 = (long)blockIdx.x * ppb, p1 = p0 + ppb < npix ? p0 + ppb : npix;
-    for (long px = p0 + pl; px < p1; px += PL) {
-        const int x = (int)(px % W); const long t = px / W; const int y = (int)(t % H); const long b = t / H;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-            const int oy = y + pad - ky;
-            if ((unsigned)oy >= (unsigned)OH) continue;
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-                const int ox = x + pad - kx;
-                if ((unsigned)ox >= (unsigned)OW) continue;
-                const float d = dy[(b * OH + oy) * OW + ox];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = fmaf(d, wr[i][ky * KW + kx], a[i]);
-            }
-        }
-        if (act) {
-            float m[4];
-            load4<T>(act + (size_t)px * C + c0, m);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] *= m[i] > 0.f ? 1.f : mslope;
-        }
-        store4<float>(g + (size_t)px * C + c0, a);
-    }
-}
-
-extern "C" int srcgan_conv1_dgrad_f32(const float* dy, const float* w, const void* act, float* g, int B, int H, int W, int OH, int OW,
-                                      int C, int kh, int kw, int pad, float mslope, int dtype, void* stream) {
-    SG_REQUIRE(dy && w && g && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "srcgan_conv1_dgrad_f32: bad arguments");
-    SG_REQUIRE(kh == 4 && kw == 4, "srcgan_conv1_dgrad_f32: 4x4 kernels only (got %dx%d)", kh, kw);
-    SG_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "srcgan_conv1_dgrad_f32: C/4 must divide 256 (C=%d)", C);
-    SG_REQUIRE(OH == H + 2 * pad - kh + 1 && OW == W + 2 * pad - kw + 1, "srcgan_conv1_dgrad_f32: extents do not match a stride-1 convolution");
-    const long npix = (long)B * H * W;
-    const int ppb = 32 * (256 / (C / 4));
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_dgrad_f32_k<T, 4, 4>), dim3((unsigned)cdivl(npix, ppb)), dim3(256), 0, (hipStream_t)stream,
-                                             dy, w, (const T*)act, g, H, W, OH, OW, C, pad, npix, mslope, ppb));
     SG_LAUNCH_CHECK();
     return 0;
 }

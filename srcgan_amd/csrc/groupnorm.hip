@@ -29,13 +29,12 @@ static inline int gn_nblk(long hw, int C, int epp) {
 
 // MODE 0: sums (x, x^2).  MODE 1: g = dy [* (yact > 0)], sums (g, g * xhat), xhat from the saved statistics.
 // partial[((b * nblk + blk) * C + c) * 2 + {0,1}]
-template <typename T, int MODE, typename TG = T>
-__global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int x_cs, const TG* __restrict__ dy, int dy_cs,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int x_cs, const T* __restrict__ dy, int dy_cs,
                                                     const T* __restrict__ yact, int ya_cs, const float* __restrict__ stats,
                                                     long hw, int C, int G, float slope, float* __restrict__ partial) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
-    typedef __attribute__((ext_vector_type(EPP))) TG vecG;      // TG = float beside T = bf16: the incoming gradient stays f32 until after the projection
     __shared__ float red[2][256 * EPP];
     const int b = blockIdx.y, nblk = gridDim.x;
     const int VG = C / EPP, PL = 256 / VG;                       // host guarantees VG | 256
@@ -56,7 +55,7 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
 #pragma unroll
             for (int i = 0; i < EPP; ++i) { const float v = to_f(xv[i]); s0[i] += v; s1[i] += v * v; }
         } else {
-            const vecG gv = *(const vecG*)(dy + q * dy_cs + c0);
+            const vecT gv = *(const vecT*)(dy + q * dy_cs + c0);
             vecT av;
             if (yact) av = *(const vecT*)(yact + q * ya_cs + c0);
 #pragma unroll
@@ -128,21 +127,19 @@ __global__ __launch_bounds__(256) void gn_apply_k(const T* __restrict__ x, int x
     }
 }
 
-template <typename T, typename TG = T, typename TR = T>
-__global__ __launch_bounds__(256) void gn_bwd_apply_k(const TG* __restrict__ dy, int dy_cs, const T* __restrict__ yact, int ya_cs, const T* __restrict__ x, int x_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_k(const T* __restrict__ dy, int dy_cs, const T* __restrict__ yact, int ya_cs, const T* __restrict__ x, int x_cs,
                                                       const float* __restrict__ gamma, const float* __restrict__ stats, const float* __restrict__ gsum,
-                                                      T* __restrict__ dx, int dx_cs, TR* __restrict__ dres, int dr_cs, int dres_acc, float slope, long hw, int C, int G, long nvec) {
+                                                      T* __restrict__ dx, int dx_cs, T* __restrict__ dres, int dr_cs, int dres_acc, float slope, long hw, int C, int G, long nvec) {
     constexpr int EPP = DT<T>::EPP;
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
-    typedef __attribute__((ext_vector_type(EPP))) TG vecG;
-    typedef __attribute__((ext_vector_type(EPP))) TR vecR;
     const int VG = C / EPP, cpg = C / G;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         const int c0 = (int)(e % VG) * EPP; const long q = e / VG; const long b = q / hw;
-        const vecG gv = *(const vecG*)(dy + q * dy_cs + c0);
+        const vecT gv = *(const vecT*)(dy + q * dy_cs + c0);
         const vecT xv = *(const vecT*)(x + q * x_cs + c0);
         vecT av; if (yact) av = *(const vecT*)(yact + q * ya_cs + c0);
-        vecT o; float gm[EPP];
+        vecT o, gm;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) {
             const int c = c0 + i, g = c / cpg;
@@ -151,20 +148,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const TG* __restrict__ dy,
             if (yact && !(to_f(av[i]) > 0.f)) gg *= slope;
             const float xh = (to_f(xv[i]) - mu) * rs;
             o[i] = from_f<T>(rs * (gg * gamma[c] - (gsum[(b * G + g) * 2] + xh * gsum[(b * G + g) * 2 + 1])));
-            gm[i] = gg;
+            gm[i] = from_f<T>(gg);
         }
         *(vecT*)(dx + q * dx_cs + c0) = o;
         if (dres) {
-            vecR r;
             if (dres_acc) {
-                const vecR old = *(const vecR*)(dres + q * dr_cs + c0);
+                const vecT old = *(const vecT*)(dres + q * dr_cs + c0);
 #pragma unroll
-                for (int i = 0; i < EPP; ++i) r[i] = from_f<TR>(gm[i] + to_f(old[i]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < EPP; ++i) r[i] = from_f<TR>(gm[i]);
+                for (int i = 0; i < EPP; ++i) gm[i] = from_f<T>(to_f(gm[i]) + to_f(old[i]));
             }
-            *(vecR*)(dres + q * dr_cs + c0) = r;
+            *(vecT*)(dres + q * dr_cs + c0) = gm;
         }
     }
 }
@@ -210,7 +203,7 @@ extern "C" int srcgan_gn_forward(const void* x, int x_cs, const void* res, int r
 
 extern "C" int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
                                   void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
-                                  float slope, int B, long hw, int C, int G, int dy_f32, int dres_f32, int dtype, float* scratch, void* stream) {
+                                  float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream) {
     SG_REQUIRE(dy && x && gamma && stats && dx && scratch, "srcgan_gn_backward: null pointer");
     SG_TRY(gn_check("srcgan_gn_backward", B, hw, C, G, dtype));
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
@@ -221,18 +214,6 @@ extern "C" int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, i
     const long nvec = (long)B * hw * (C / epp);
     float* chan = scratch + (size_t)B * GN_MAXBLK * C * 2;
     float* gsum = chan + (size_t)B * C * 2;
-    if (dtype == SRCGAN_BF16 && (dy_f32 || dres_f32)) {
-        using T = __bf16;
-#define SG_GN_BWD(TG_, TR_) do { \
-        hipLaunchKernelGGL((gn_partial_k<T, 1, TG_>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const TG_*)dy, dy_cs, (const T*)yact, ya_cs, stats, hw, C, G, slope, scratch); \
-        hipLaunchKernelGGL(gn_fold_k<1>, dim3(B), dim3(256), 0, st, (const float*)scratch, nblk, C, G, hw, 0.f, gamma, gsum, chan); \
-        hipLaunchKernelGGL((gn_bwd_apply_k<T, TG_, TR_>), dim3(ew_blocks(nvec)), dim3(256), 0, st, (const TG_*)dy, dy_cs, (const T*)yact, ya_cs, (const T*)x, x_cs, gamma, stats, \
-                           (const float*)gsum, (T*)dx, dx_cs, (TR_*)dres, dres_cs, dres_accumulate, slope, hw, C, G, nvec); } while (0)
-        if (dy_f32 && dres_f32) SG_GN_BWD(float, float);
-        else if (dy_f32) SG_GN_BWD(float, T);
-        else SG_GN_BWD(T, float);
-#undef SG_GN_BWD
-    } else
     DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((gn_partial_k<T, 1>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)yact, ya_cs, stats, hw, C, G, slope, scratch);
         hipLaunchKernelGGL(gn_fold_k<1>, dim3(B), dim3(256), 0, st, (const float*)scratch, nblk, C, G, hw, 0.f, gamma, gsum, chan);

@@ -16,6 +16,7 @@
 #include <vector>
 #include <map>
 #include <string>
+#include <mutex>
 
 namespace {
 
@@ -43,8 +44,6 @@ struct Conv {
     Conv& res1(TRef r, int cend, float beta) { d.r1 = r.p; d.r1_cs = r.cs; d.r1_coff = r.coff; d.r1_plane = r.plane; d.r1_cend = cend; d.beta1 = beta; return *this; }
     Conv& res2(TRef r, int cend, float beta) { d.r2 = r.p; d.r2_cs = r.cs; d.r2_coff = r.coff; d.r2_plane = r.plane; d.r2_cend = cend; d.beta2 = beta; return *this; }
     Conv& lrelu() { d.act = 1; return *this; }
-    Conv& out_f32(bool on = true) { d.y_f32 = on ? 1 : 0; return *this; }       // the output feeds a normalisation backward: keep it f32
-    Conv& res1_f32(bool on = true) { d.r1_f32 = on ? 1 : 0; return *this; }
     Conv& sign_out(void* m) { d.sign_out = m; return *this; }                  // write / read the LeakyReLU sign mask (u32 per pixel)
     Conv& sign_in(const void* m) { d.sign_in = m; return *this; }
     Conv& mask(TRef z, int c0) { d.mz = z.p; d.mz_cs = z.cs; d.mz_coff = z.coff; d.mz_plane = z.plane; d.mz_c0 = c0; return *this; }
@@ -92,6 +91,7 @@ static int bias_grad(int dtype, TRef dy, long npix, int C, float scale, float* o
 // ---- batched weight packing with a cached device-side job table
 struct PackCache { std::vector<SgPackJob> host; SgPackJob* dev = nullptr; size_t cap = 0; };
 static std::map<std::string, PackCache> g_pack_cache;
+static std::mutex g_pack_mutex;
 
 struct PackList {
     std::vector<SgPackJob> jobs; long nblk = 0; int dtype; char* base;
@@ -107,17 +107,24 @@ struct PackList {
     }
     int run(const char* tag, const void* key_ptr, void* st) {
         if (jobs.empty()) return 0;
-        char key[96];
-        snprintf(key, sizeof(key), "%s:%p:%d:%zu", tag, key_ptr, dtype, jobs.size());
+        int dev = 0;
+        SG_HIP(hipGetDevice(&dev));
+        char key[112];
+        snprintf(key, sizeof(key), "%s:%d:%p:%d:%zu", tag, dev, key_ptr, dtype, jobs.size());
+        std::lock_guard<std::mutex> lock(g_pack_mutex);
         PackCache& c = g_pack_cache[key];
         const size_t bytes = jobs.size() * sizeof(SgPackJob);
         if (c.host.size() != jobs.size() || memcmp(c.host.data(), jobs.data(), bytes) != 0) {
+            // cold path (first call / parameters or buffers moved): an earlier pack kernel on this stream may still be reading
+            // the table, so the stream is drained before the table is replaced (a blocking copy alone orders nothing
+            // against a non-blocking stream)
+            SG_HIP(hipStreamSynchronize((hipStream_t)st));
             if (c.cap < bytes) {
                 if (c.dev) SG_HIP(hipFree(c.dev));
                 SG_HIP(hipMalloc((void**)&c.dev, bytes));
                 c.cap = bytes;
             }
-            SG_HIP(hipMemcpy(c.dev, jobs.data(), bytes, hipMemcpyHostToDevice));     // cold path: first call / parameters moved
+            SG_HIP(hipMemcpy(c.dev, jobs.data(), bytes, hipMemcpyHostToDevice));
             c.host = jobs;
         }
         return sg_pack_multi_launch(c.dev, (int)jobs.size(), nblk, base, dtype, (hipStream_t)st);
@@ -294,15 +301,20 @@ extern "C" size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c) 
     RddbBwdPlan Q; rddb_bwd_plan(c, P, Q); return Q.total;
 }
 
-extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
-                                      void* ws, float* y_nchw, void* st) {
+extern "C" size_t srcgan_rddbnet_wpack_bytes(const srcgan_rddbnet_cfg* c) { RddbPlan P; if (rddb_plan(c, P)) return 0; return P.total - P.wpk; }
+
+extern "C" int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
+                                         void* ws, float* y_nchw, const srcgan_net_opts* opt, void* st) {
     RddbPlan P;
     SG_TRY(rddb_plan(c, P));
     SG_REQUIRE(x_nchw && params && ws && y_nchw, "srcgan_rddbnet_forward: null pointer");
     SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_rddbnet_forward: workspace must be 256-byte aligned");
     const int dt = c->dtype, nf = c->nf, gc = c->gc, B = c->B;
     char* w8 = (char*)ws;
-    char* wp = w8 + P.wpk;
+    // packed weights: a persistent buffer of the caller's (packed once per optimiser step) or a region of this call's workspace
+    char* wp = (opt && opt->wpack) ? (char*)opt->wpack : w8 + P.wpk;
+    SG_REQUIRE(((uintptr_t)wp % 256) == 0, "srcgan_rddbnet_forward: wpack must be 256-byte aligned");
+    const bool do_pack = !(opt && opt->wpack) || opt->pack;
     auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
     auto Abuf = [&](int r) { return tref(w8 + P.A + (size_t)r * P.szA, P.kce, 0, P.plane_bytes); };
 
@@ -324,7 +336,7 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
         packs.add(params[P.p_lg[k]], wp + P.lw_f[k], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     packs.add(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
 
-    SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : P.legacy == 3 ? "srdn_fwd" : "rddb_fwd", params[0], st));
+    if (do_pack) SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : P.legacy == 3 ? "srdn_fwd" : "rddb_fwd", params[0], st));
 
     // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -411,8 +423,13 @@ extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* 
     return 0;
 }
 
-extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
-                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+extern "C" int srcgan_rddbnet_forward(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
+                                      void* ws, float* y_nchw, void* st) {
+    return srcgan_rddbnet_forward_ex(c, x_nchw, params, ws, y_nchw, nullptr, st);
+}
+
+extern "C" int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
+                                          void* ws, void* scratch, float* const* grads, float* dx_nchw, const srcgan_net_opts* opt, void* st) {
     RddbPlan P;
     SG_TRY(rddb_plan(c, P));
     RddbBwdPlan Q;
@@ -420,7 +437,19 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "srcgan_rddbnet_backward: null pointer");
     SG_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)scratch % 256) == 0, "srcgan_rddbnet_backward: buffers must be 256-byte aligned");
     const int dt = c->dtype, nf = c->nf, gc = c->gc, B = c->B, H = P.Ht, W = P.Wt;
-    char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
+    char* w8 = (char*)ws; char* s8 = (char*)scratch;
+    char* wp = (opt && opt->wpack) ? (char*)opt->wpack : w8 + P.wpk;
+    const bool do_pack = !(opt && opt->wpack) || opt->pack;
+    // Phased backward (data parallel: the gradients of the RRDBs a phase covers are final when it returns, so their all-reduce
+    // starts while earlier blocks still compute).  A call handles the RRDBs [lo, hi), last to first; the call with hi == nrr also
+    // runs everything behind the trunk (conv_last, up-sampler, trunk_conv), the call with lo == 0 everything in front of it
+    // (conv_first / down-sampling stages, dx).  Calls must come in descending, gap-free order on one stream with the same
+    // scratch: the running gradient sits in the scratch between them.
+    int r_lo = 0, r_hi = P.nrr;
+    if (opt && opt->rrdb_hi > 0) { r_lo = opt->rrdb_lo; r_hi = opt->rrdb_hi; }
+    SG_REQUIRE(r_lo >= 0 && r_lo <= r_hi && r_hi <= P.nrr, "srcgan_rddbnet_backward: RRDB range [%d,%d) outside [0,%d)", r_lo, r_hi, P.nrr);
+    SG_REQUIRE(P.nrr > 0 || (r_lo == 0), "srcgan_rddbnet_backward: a network without a trunk has one phase");
+    const bool first_phase = r_hi == P.nrr, last_phase = r_lo == 0;
     float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr);
     auto T_ = [&](size_t off, int cs) { return tref(w8 + off, cs); };
     auto S_ = [&](size_t off, int cs) { return tref(s8 + off, cs); };
@@ -429,7 +458,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     const long npix_t = (long)B * H * W;
 
     // ---- packed dgrad weights (flipped / transposed views of the canonical tensors): ONE batched launch
-    {
+    const bool pack_dx = dx_nchw || (opt && opt->wpack);       // a persistent pack serves later calls that may want dx
+    if (first_phase && do_pack) {
         PackList packs(dt, wp);
         const WLayout L = lay_dgrad_s1(nf, 3, 3);
         packs.add(params[P.p_last_w], wp + P.w_last_d, nf, c->out_ch, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
@@ -459,19 +489,20 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
                 const long off = (a ? 2 : 1) * 3 + (bb ? 2 : 1);
                 packs.add(params[P.p_dn0 + 2 * s], wp + P.w_dn_d[s][q], nf, nf, ty, tx, 9, (long)nf * 9, -6, -2, off);
             }
-        if (dx_nchw) {
+        if (pack_dx) {
             const WLayout L0 = lay_dgrad_s1(c->in_ch, 3, 3);
             packs.add(params[P.p_first_w], wp + P.w_first_d, c->in_ch, nf, 3, 3, L0.sr, L0.sk, L0.sty, L0.stx, L0.off);
         }
-        SG_TRY(packs.run(P.legacy == 1 ? (dx_nchw ? "rddbB_bwd_dx" : "rddbB_bwd") : P.legacy == 2 ? (dx_nchw ? "rddbL_bwd_dx" : "rddbL_bwd")
-                                       : P.legacy == 3 ? (dx_nchw ? "srdn_bwd_dx" : "srdn_bwd")
-                                       : (dx_nchw ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st));
+        SG_TRY(packs.run(P.legacy == 1 ? (pack_dx ? "rddbB_bwd_dx" : "rddbB_bwd") : P.legacy == 2 ? (pack_dx ? "rddbL_bwd_dx" : "rddbL_bwd")
+                                       : P.legacy == 3 ? (pack_dx ? "srdn_bwd_dx" : "srdn_bwd")
+                                       : (pack_dx ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st));
     }
 
     // ---- dy: NCHW f32 -> NHWC
     TRef dout = S_(Q.dout, P.out_cs);
-    SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dout.p, B, c->out_ch, P.HO, P.WO, P.out_cs, dt, st));
     TRef dU0 = S_(Q.dU[0], nf);
+    if (first_phase) {
+    SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dout.p, B, c->out_ch, P.HO, P.WO, P.out_cs, dt, st));
     if (P.legacy == 1 || P.legacy == 2) {
         // ---- legacy tail backward.  dcur = gradient w.r.t. an op's output, already times LeakyReLU' of that output.
         TRef tin = P.legacy == 2 ? Abuf(0) : T_(P.U[0], nf);          // tail input (not an activation output)
@@ -540,11 +571,12 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         SG_TRY(cv.run(st));
     }
     }
+    }                            // first_phase: everything behind the trunk
     TRef dfea = dU0;
     if (P.legacy != 2) {
     // U0 = fea + trunk_conv(T): d(trunk_conv out) = dU0, d(fea) += dU0 (joined at the end)
     TRef Tt = T_(P.T, nf), dT = S_(Q.dT, nf);
-    if (P.legacy != 3) {
+    if (first_phase && P.legacy != 3) {
     if (G(P.p_trunk_w))
         SG_TRY(wgrad_call(dt, dU0, H, W, nf, Tt, B, H, W, nf, 3, 3, 1, 1, 1, lay_fwd(nf, 3, 3), 1.f, slab, G(P.p_trunk_w), st, G(P.p_trunk_b)));
     else if (G(P.p_trunk_b)) SG_TRY(bias_grad(dt, dU0, npix_t, nf, 1.f, G(P.p_trunk_b), colscr, st));
@@ -554,7 +586,8 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     // dy5..dy_{j+1} (composite transposed weights), so every gradient element is written exactly once: no
     // read-modify-write accumulation, and the same prefix-read / slice-write pattern as forward.
     auto Pg = [&](int g) { return tref(s8 + Q.Pg[g], P.kce, 0, P.plane_bytes); };
-    if (P.legacy == 3) {
+    if (!first_phase) {
+    } else if (P.legacy == 3) {
         // SRDN: d(decoder output) = d(fea2) = dU0 itself (no trunk_conv): into the first gradient buffer's channels [0,nf)
         TRef g0 = Pg(0);
         SG_HIP(hipMemsetAsync(g0.p, 0, (size_t)cdiv(nf, P.kce) * P.plane_bytes, (hipStream_t)st));
@@ -562,7 +595,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
     } else
     SG_TRY(Conv(dt, 3, 3, 1).in(dU0, B, H, W, nf).w(wp + P.w_trunk_d).out(Pg(0), H, W, nf).pad(1, 1).run(st));
     (void)dT;
-    for (int i = P.nrr - 1; i >= 0; --i) {
+    for (int i = r_hi - 1; i >= r_lo; --i) {
         if (P.legacy == 3 && i == c->nb - 1) {
             // between the stacks: d(fea1) = d(fea2) + d(decoder input); it feeds the encoder's output AND the skip around it
             TRef g0 = Pg(0);
@@ -611,6 +644,7 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
             }
         }
     }
+    if (!last_phase) return 0;
     TRef dcur = Pg(0);
     // gradient w.r.t. the trunk input feature = dcur + dU0 (global skip); for the HR->LR variant the trunk input
     // is a LeakyReLU output, so its derivative is applied in the same pass.
@@ -647,6 +681,11 @@ extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float*
         SG_TRY(srcgan_nhwc_to_nchw_f32(dxin.p, dx_nchw, B, c->in_ch, c->H, c->W, P.in_cs, 0, dt, st));
     }
     return 0;
+}
+
+extern "C" int srcgan_rddbnet_backward(const srcgan_rddbnet_cfg* c, const float* dy_nchw, const float* const* params,
+                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+    return srcgan_rddbnet_backward_ex(c, dy_nchw, params, ws, scratch, grads, dx_nchw, nullptr, st);
 }
 
 // ======================================================================================== NLayerDiscriminator
@@ -727,21 +766,14 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     return 0;
 }
 
-struct DBwdPlan { size_t dO, g, dz, dxin, slab, colscr, sums, gfold, total; };
+struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, gfold, total; };
 static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q) {
     const size_t e = P.esz, B = c->B;
     Bump b;
     Q.dO = b.take(B * P.hh[P.L] * P.ww[P.L] * P.out_cs * e);
-    // g: the gradient w.r.t. a layer's output as its consumer's input-gradient convolution leaves it (times LeakyReLU'): f32 when
-    // that layer ends in a BatchNorm (its backward projection cancels most of g: rounded to the compute dtype only afterwards);
-    // dz: the BatchNorm backward's result in the compute dtype, operand of that layer's weight- and input-gradient convolutions.
-    size_t mg = 0, mz = 0;
-    for (int l = 0; l < P.L - 1; ++l) {
-        const bool bn = P.bn_idx[l] >= 0;
-        size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * (bn ? 4 : e); if (s > mg) mg = s;
-        if (bn) { s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mz) mz = s; }
-    }
-    Q.g = b.take(mg); Q.dz = b.take(mz ? mz : 256);
+    size_t mx = 0;
+    for (int l = 0; l < P.L - 1; ++l) { size_t s = B * P.hh[l + 1] * P.ww[l + 1] * P.ch[l + 1] * e; if (s > mx) mx = s; }
+    Q.g[0] = b.take(mx); Q.g[1] = b.take(mx);
     Q.dxin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);
     Q.gfold = b.take((size_t)P.ch[1] * 32 * 4 * sizeof(float));
     size_t slab = 0;
@@ -767,15 +799,28 @@ extern "C" size_t srcgan_nlayerd_bwd_scratch_bytes(const srcgan_nlayerd_cfg* c) 
     DPlan P; if (d_plan(c, P)) return 0; DBwdPlan Q; d_bwd_plan(c, P, Q); return Q.total;
 }
 
+extern "C" size_t srcgan_nlayerd_wpack_bytes(const srcgan_nlayerd_cfg* c) { DPlan P; if (d_plan(c, P)) return 0; return P.total - P.wpk; }
+
 extern "C" int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* x_nchw, const float* const* params,
                                       float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw, void* st) {
+    return srcgan_nlayerd_forward_ex(c, x_nchw, params, bn_running, bn_nbt, ws, y_nchw, nullptr, st);
+}
+extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
+                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+    return srcgan_nlayerd_backward_ex(c, dy_nchw, params, ws, scratch, grads, dx_nchw, nullptr, st);
+}
+
+extern "C" int srcgan_nlayerd_forward_ex(const srcgan_nlayerd_cfg* c, const float* x_nchw, const float* const* params,
+                                         float* const* bn_running, int64_t* const* bn_nbt, void* ws, float* y_nchw,
+                                         const srcgan_net_opts* opt, void* st) {
     DPlan P;
     SG_TRY(d_plan(c, P));
     SG_REQUIRE(x_nchw && params && ws && y_nchw, "srcgan_nlayerd_forward: null pointer");
     SG_REQUIRE(((uintptr_t)ws % 256) == 0, "srcgan_nlayerd_forward: workspace must be 256-byte aligned");
     const int dt = c->dtype, B = c->B;
-    char* w8 = (char*)ws; char* wp = w8 + P.wpk;
-    {
+    char* w8 = (char*)ws; char* wp = (opt && opt->wpack) ? (char*)opt->wpack : w8 + P.wpk;
+    SG_REQUIRE(((uintptr_t)wp % 256) == 0, "srcgan_nlayerd_forward: wpack must be 256-byte aligned");
+    if (!(opt && opt->wpack) || opt->pack) {
         PackList packs(dt, wp);
         for (int l = 0; l < P.L; ++l) {
             if (l == 0 && P.s2d) {
@@ -831,8 +876,8 @@ extern "C" int srcgan_nlayerd_forward(const srcgan_nlayerd_cfg* c, const float* 
     return 0;
 }
 
-extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
-                                       void* ws, void* scratch, float* const* grads, float* dx_nchw, void* st) {
+extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const float* dy_nchw, const float* const* params,
+                                          void* ws, void* scratch, float* const* grads, float* dx_nchw, const srcgan_net_opts* opt, void* st) {
     DPlan P;
     SG_TRY(d_plan(c, P));
     SG_REQUIRE(c->training, "srcgan_nlayerd_backward: backward through eval-mode BatchNorm is not supported");
@@ -840,12 +885,13 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
     DBwdPlan Q;
     d_bwd_plan(c, P, Q);
     const int dt = c->dtype, B = c->B;
-    char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = w8 + P.wpk;
+    char* w8 = (char*)ws; char* s8 = (char*)scratch; char* wp = (opt && opt->wpack) ? (char*)opt->wpack : w8 + P.wpk;
     float* slab = (float*)(s8 + Q.slab); float* colscr = (float*)(s8 + Q.colscr); float* sums = (float*)(s8 + Q.sums);
     // ---- packed dgrad weights
+    const bool pack_dx = dx_nchw || (opt && opt->wpack);       // a persistent pack serves later calls that may want dx
     PackList packs(dt, wp);
-    for (int l = 0; l < P.L; ++l) {
-        if (l == 0 && !dx_nchw) continue;
+    for (int l = 0; l < P.L && (!(opt && opt->wpack) || opt->pack); ++l) {
+        if (l == 0 && !pack_dx) continue;
         const int cin = P.ch[l], cout = P.ch[l + 1];
         if (l == 0 && P.s2d) {
             // dX'[j,i,(dy,dx,c)] = sum_{u,v,co} dY[j-1+u, i-1+v, co] * W[co][c][2(1-u)+dy][2(1-v)+dx]: rows (dy,dx,c8), k = co, 2x2 taps.
@@ -868,8 +914,8 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
                 packs.add(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off);
             }
     }
-    SG_TRY(packs.run(P.s2d ? (dx_nchw ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (dx_nchw ? "d_bwd_dx" : "d_bwd"), params[0], st));
-    // ---- dy -> NHWC (1 channel, padded with zeros to 8): operand of the prediction layer's weight gradient
+    SG_TRY(packs.run(P.s2d ? (pack_dx ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (pack_dx ? "d_bwd_dx" : "d_bwd"), params[0], st));
+    // ---- dy -> NHWC (1 channel, padded with zeros to 8)
     const int Lh = P.hh[P.L], Lw = P.ww[P.L];
     TRef dcur = tref(s8 + Q.dO, P.out_cs);
     SG_TRY(srcgan_nchw_f32_to_nhwc(dy_nchw, dcur.p, B, 1, Lh, Lw, P.out_cs, dt, st));
@@ -880,16 +926,13 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
         const long npix = (long)B * oh * ow;
         const bool bn = P.bn_idx[l] >= 0;
         if (bn) {
-            // g (f32) = dL/dy * lrelu'(y), written by the consumer's input-gradient kernel.  BN backward (train): sum g, sum g*xhat
-            // in f32 from the f32 g, then dz = gamma*rstd*(g - mean g - xhat*mean(g xhat)) rounded ONCE to the compute dtype.
+            // dcur = dL/dy * lrelu'(y) (mask fused in the producer).  BN backward (train): needs sum g, sum g*xhat
             float* mean = (float*)(w8 + P.stat[l]); float* rstd = mean + 2 * cout;
             TRef z = tref(w8 + P.Z[l], cout);
-            const void* g32 = s8 + Q.g;
-            SG_TRY(srcgan_col_reduce(3, g32, cout, 0, z.p, cout, 0, mean, rstd, npix, cout, 1.f, sums, sums + cout, colscr, dt, st));
+            SG_TRY(srcgan_col_reduce(2, dcur.p, dcur.cs, 0, z.p, cout, 0, mean, rstd, npix, cout, 1.f, sums, sums + cout, colscr, dt, st));
             if (grads[P.pbeta[l]]) SG_HIP(hipMemcpyAsync(grads[P.pbeta[l]], sums, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
             if (grads[P.pg[l]]) SG_HIP(hipMemcpyAsync(grads[P.pg[l]], sums + cout, cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-            dcur = tref(s8 + Q.dz, cout); dcur_c = cout;
-            SG_TRY(srcgan_bn_bwd_apply(g32, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, 1, dt, st));
+            SG_TRY(srcgan_bn_bwd_apply(dcur.p, z.p, dcur.p, mean, rstd, params[P.pg[l]], sums, sums + cout, npix, cout, cout, dt, st));
         }
         TRef xin_l = l == 0 ? tref(w8 + P.xin, P.s2d ? 32 : P.in_cs) : tref(w8 + P.Y[l - 1], cin);
         if (grads[P.pw[l]]) {
@@ -909,16 +952,12 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
             SG_TRY(srcgan_s2d_to_nchw_f32(dst.p, dx_nchw, B, c->in_ch, c->H, c->W, dt, st));
             return 0;
         }
-        const bool to_bn = l >= 1 && P.bn_idx[l - 1] >= 0;          // the result enters layer l-1's BatchNorm backward: f32
-        TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g, cin);
+        TRef dst = l == 0 ? tref(s8 + Q.dxin, P.in_cs) : tref(s8 + Q.g[l & 1], cin);
         if (l == 0) SG_HIP(hipMemsetAsync(dst.p, 0, (size_t)B * ih * iw * P.in_cs * P.esz, (hipStream_t)st));
         TRef mz = l == 0 ? TNULL : tref(w8 + P.Y[l - 1], cin);
-        if (l == P.L - 1 && to_bn && cin % 4 == 0 && cin / 4 <= 256 && 256 % (cin / 4) == 0) {
-            // prediction layer (one output channel): f32 throughout, straight from the f32 dy autograd handed over
-            SG_TRY(srcgan_conv1_dgrad_f32(dy_nchw, params[P.pw[l]], mz.p, (float*)dst.p, B, ih, iw, oh, ow, cin, 4, 4, 1, 0.2f, dt, st));
-        } else if (P.st[l] == 1) {
+        if (P.st[l] == 1) {
             Conv cv(dt, 4, 4, 1);
-            cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, ih, iw, cin).pad(2, 2).out_f32(to_bn);
+            cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, ih, iw, cin).pad(2, 2);
             if (mz.p) cv.mask(mz, 0);
             SG_TRY(cv.run(st));
         } else {
@@ -927,7 +966,7 @@ extern "C" int srcgan_nlayerd_backward(const srcgan_nlayerd_cfg* c, const float*
                 const int mh = (ih - a + 1) / 2, mw = (iw - bb + 1) / 2;
                 if (mh <= 0 || mw <= 0) continue;
                 Conv cv(dt, 2, 2, 1);
-                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][q]).out(dst, mh, mw, cin).pad(a ? 0 : 1, bb ? 0 : 1).scatter(2, a, bb, ih, iw).out_f32(to_bn);
+                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][q]).out(dst, mh, mw, cin).pad(a ? 0 : 1, bb ? 0 : 1).scatter(2, a, bb, ih, iw);
                 if (mz.p) cv.mask(mz, 0);
                 SG_TRY(cv.run(st));
             }
@@ -964,7 +1003,6 @@ struct RdPlan {
     std::vector<RdT> T; std::vector<RdOp> ops;
     size_t xin, gnfwd, wpk, total, act_bytes;
     std::vector<size_t> g;    // backward: gradient buffer offsets (scratch), same shapes as T
-    std::vector<char> gf32;   // gradient tensor holds f32 elements (it enters a GroupNorm backward) although the compute dtype is narrower
     size_t slab, gnscr, colscr, bwd_total;
 };
 
@@ -1046,13 +1084,9 @@ struct RdBuilder {
         // backward scratch
         Bump s;
         P.g.resize(P.T.size());
-        // The gradient of a GroupNorm OUTPUT enters that GroupNorm's backward projection (g - mean g - xhat mean(g xhat) cancels
-        // most of it): such gradient tensors are f32 whatever the compute dtype, rounded once after the projection.
-        P.gf32.assign(P.T.size(), 0);
-        if (P.esz != 4) for (const RdOp& o : P.ops) if (o.type == 1) P.gf32[o.out] = 1;
         long maxpix = 1;
         for (size_t i = 0; i < P.T.size(); ++i) {
-            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * (P.gf32[i] ? 4 : P.esz));
+            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
             if ((long)B * P.T[i].H * P.T[i].W > maxpix) maxpix = (long)B * P.T[i].H * P.T[i].W;
         }
         size_t slab = 0;
@@ -1233,13 +1267,10 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         const bool need_dx = o.in != 0;
         TRef dx = need_dx ? gt(o.in) : TNULL;
         bool acc = need_dx && written[o.in];
-        const bool dx32 = need_dx && P.gf32[o.in];       // the input's gradient tensor is f32 (it enters a GroupNorm backward)
         if (o.type == 0) {
-            SG_REQUIRE(!P.gf32[o.out], "%s backward: internal error (f32 gradient of a convolution output)", tag);
             if (o.res >= 0) {       // y = conv(x) + res: the residual's gradient is dy itself
                 const RdT tr = P.T[o.res];
                 TRef dr = gt(o.res);
-                SG_REQUIRE(!P.gf32[o.res], "%s backward: a convolution's residual operand produced by a GroupNorm is not supported in bf16", tag);
                 if (!written[o.res]) SG_HIP(hipMemcpyAsync(dr.p, dy.p, (size_t)B * tr.H * tr.W * tr.cs * P.esz, hipMemcpyDeviceToDevice, (hipStream_t)st));
                 else SG_TRY(srcgan_add_inplace(dr.p, tr.cs, 0, dy.p, to.cs, 0, nullptr, 0, 0, 0.f, (long)B * tr.H * tr.W, tr.C, dt, st));
                 written[o.res] = 1;
@@ -1254,23 +1285,23 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
                 SG_REQUIRE(!(acc && ti.act), "%s backward: internal error (activated tensor with two consumers)", tag);
                 if (o.s == 1) {
                     Conv cv(dt, o.k, o.k, 1);
-                    cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad).out_f32(dx32);
-                    if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
+                    cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad);
+                    if (acc) cv.res1(dx, ti.C, 1.f);
                     if (ti.act) { cv.mask(xin, 0); cv.d.mslope = 0.f; }
                     SG_TRY(cv.run(st));
                 } else if (o.k == 1) {
-                    if (!acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * (dx32 ? 4 : P.esz), (hipStream_t)st));
+                    if (!acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * P.esz, (hipStream_t)st));
                     Conv cv(dt, 1, 1, 1);
-                    cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, to.H, to.W, ti.C).pad(0, 0).scatter(2, 0, 0, ti.H, ti.W).out_f32(dx32);
-                    if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
+                    cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, to.H, to.W, ti.C).pad(0, 0).scatter(2, 0, 0, ti.H, ti.W);
+                    if (acc) cv.res1(dx, ti.C, 1.f);
                     SG_TRY(cv.run(st));
                 } else {
                     for (int q = 0; q < 4; ++q) {
                         const int a = q >> 1, bb = q & 1;
                         const int mh = (ti.H - a + 1) / 2, mw = (ti.W - bb + 1) / 2;
                         Conv cv(dt, a ? 2 : 1, bb ? 2 : 1, 1);
-                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(0, 0).scatter(2, a, bb, ti.H, ti.W).out_f32(dx32);
-                        if (acc) cv.res1(dx, ti.C, 1.f).res1_f32(dx32);
+                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(0, 0).scatter(2, a, bb, ti.H, ti.W);
+                        if (acc) cv.res1(dx, ti.C, 1.f);
                         SG_TRY(cv.run(st));
                     }
                 }
@@ -1284,19 +1315,17 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
             SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (GroupNorm input has two consumers or a fused activation)", tag);
             const int pacc = seen_param[o.w];       // a GroupNorm module applied more than once (edsr.py:41,47,49): gradients add
             seen_param[o.w] = 1;
-            SG_REQUIRE(!dx32, "%s backward: internal error (GroupNorm input produced by a GroupNorm)", tag);
             SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, params[o.w], (const float*)(w8 + o.stats),
-                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32,
-                                      P.gf32[o.out], o.res >= 0 && P.gf32[o.res], dt, gnscr, st));
+                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
             written[o.in] = 1;
         } else if (o.type == 2) {
             if (G(o.w))     // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2
                 SG_TRY(wgrad_call(dt, xin, ti.H, ti.W, ti.C, dy, B, to.H, to.W, to.C, 2, 2, 2, 0, 0, WLayout{(long)to.C * 4, 4, 2, 1, 0}, 1.f, slab, G(o.w), st));
-            SG_REQUIRE(!acc && !ti.act && !P.gf32[o.out], "%s backward: internal error (deconvolution input)", tag);
-            SG_TRY(Conv(dt, 2, 2, 2).in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(0, 0).out_f32(dx32).run(st));
+            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (deconvolution input)", tag);
+            SG_TRY(Conv(dt, 2, 2, 2).in(dy, B, to.H, to.W, to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(0, 0).run(st));
             written[o.in] = 1;
         } else {
-            SG_REQUIRE(!acc && !ti.act && !dx32 && !P.gf32[o.out], "%s backward: internal error (PixelShuffle input)", tag);
+            SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (PixelShuffle input)", tag);
             SG_TRY(srcgan_pixel_shuffle_nhwc(dy.p, to.cs, dx.p, ti.cs, B, ti.H, ti.W, to.C, o.k, 1, dt, st));
             written[o.in] = 1;
         }

@@ -1,13 +1,18 @@
 """Data-parallel replicas: one process per GPU, torch.distributed ('nccl' == RCCL over xGMI on ROCm;
 'gloo' for the CPU tests).  The reference has no distributed code at all;
-this is the build's addition: parameter broadcast at start (C1) and bucketed, asynchronous gradient
-all-reduce (C2) that the optimiser step waits on.
+this is the build's addition: parameter broadcast at start (C1) and the gradient mean (C2).
 
 Images are independent units, so the hot path shards with no data-path collective; the only exchange
-is the gradient mean.  Buckets are flattened into one contiguous buffer each (few, large collectives:
-xGMI is point-to-point, ring steps are per-link bound) and reduced on a side stream so the copy-in of
-bucket k+1 overlaps the collective of bucket k; BatchNorm statistics stay per replica (no SyncBN),
-as single-device reference semantics imply.
+is the gradient mean.  It happens INSIDE every native backward call (``GradSync.attach``): the call writes
+its parameter gradients into one flat f32 arena, the generator's backward runs in phases over RRDB ranges
+(``srcgan_net_opts.rrdb_lo/hi``), and when a phase has been queued the arena slice it finalised is
+all-reduced in place on a side stream (<= bucket_mb pieces: few, large collectives -- xGMI is
+point-to-point, ring steps are per-link bound) while the next phase computes on the main stream.  What
+autograd receives from ``backward`` is already the mean over replicas, so the harnesses need no separate
+synchronisation step and a network called several times per step (the cycle's generators, train.py:228-260)
+simply averages each contribution.  BatchNorm statistics stay per replica (no SyncBN), as single-device
+reference semantics imply.  ``GradSync.allreduce(params)`` is the plain post-backward form (bucketed,
+asynchronous, flatten + copy-back) for anything that is not one of this package's networks.
 """
 from __future__ import annotations
 
@@ -80,12 +85,78 @@ class GradSync:
     launches every all-reduce asynchronously and writes the averaged values back before returning the
     stream to the optimiser.  Parameters without a gradient (frozen discriminator, train.py:330) are skipped."""
 
-    def __init__(self, bucket_mb: float = 32.0, group=None):
+    def __init__(self, bucket_mb: float = 32.0, group=None, phases: int = 4):
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._active = self.world > 1 or (_FORCE and dist.is_initialized())
         self._side = torch.cuda.Stream() if torch.cuda.is_available() and self._active else None
+        self.phases = max(1, int(phases))
+        self.attached = False
+        self.stats = {"calls": 0, "phases": 0, "collectives": 0, "bytes": 0}
+
+    # ---- in-backward form -------------------------------------------------------------------------------------------
+    def attach(self) -> "GradSync":
+        """Average gradients inside every native backward of this package's networks (see the module docstring)."""
+        from . import model
+        for kind in ("rddb", "nlayerd", "resdeconv", "srnet"):
+            model._phase_hooks[kind] = self
+        self.attached = True
+        return self
+
+    def detach(self) -> None:
+        from . import model
+        for kind, h in list(model._phase_hooks.items()):
+            if h is self:
+                del model._phase_hooks[kind]
+        self.attached = False
+
+    def cuts(self, cfg, nrr: int) -> List[int]:
+        """Phase boundaries (RRDB indices) of a generator backward: ``phases`` near-equal RRDB ranges.  Only the plain RDDBNet /
+        RDDBNetA parameter order (conv_first, [down], RRDBs, trunk_conv, up-sampler, conv_last) is phased."""
+        if not self._active or cfg.legacy != 0 or nrr < 2:
+            return [0]
+        k = min(self.phases, nrr)
+        return sorted({(nrr * j) // k for j in range(k)})
+
+    @torch.no_grad()
+    def phase_done(self, arena, params, cfg, lo: int, hi: int, nrr: int) -> None:
+        """The native call that finalised the gradients of RRDBs [lo, hi) (+ tail if hi == nrr, + head if lo == 0; everything when
+        nrr == 0) has been queued on the current stream: reduce that slice of the arena on the side stream, in place."""
+        if not self._active or arena is None or arena.flat.numel() == 0:
+            return
+        n = len(params)
+        if nrr > 0 and not (lo == 0 and hi == nrr):
+            ndn = 0
+            d = int(getattr(cfg, "down", 0))
+            while d > 1:
+                ndn, d = ndn + 1, d >> 1
+            p_rdb0 = 2 + 2 * ndn
+            i0 = p_rdb0 + 30 * lo if lo > 0 else 0
+            i1 = n if hi == nrr else p_rdb0 + 30 * hi
+        else:
+            i0, i1 = 0, n
+        a, b = arena.offsets[i0], arena.offsets[i1]
+        last = (lo == 0)
+        flat = arena.flat
+        cuda = flat.is_cuda
+        main = torch.cuda.current_stream(flat.device) if cuda else None
+        if cuda:
+            self._side.wait_stream(main)                      # the phase's kernels
+        self.stats["phases"] += 1
+        with self._ctx(cuda):
+            step = max(1, self.bucket_bytes // 4)
+            for o in range(a, b, step):
+                piece = flat[o:min(o + step, b)]
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                piece.mul_(1.0 / self.world)
+                self.stats["collectives"] += 1
+                self.stats["bytes"] += piece.numel() * 4
+        if last:
+            self.stats["calls"] += 1
+            if cuda:
+                main.wait_stream(self._side)                  # autograd / the optimiser see averaged gradients
+                flat.record_stream(self._side)
 
     def _buckets(self, grads: List[torch.Tensor]) -> List[List[torch.Tensor]]:
         out, cur, size = [], [], 0

@@ -79,6 +79,54 @@ def _kaiming_like_reference(module: nn.Module) -> None:
             nn.init.constant_(m.bias, 0)
 
 
+class _PackState:
+    """Persistent packed (MFMA-order, compute-dtype) copy of a module's weights: packed once per weight update instead of once per
+    native call -- a cycle step runs each generator three times forward and three times backward on the same weights
+    (reference train.py:228-260, 331-333).  Validity is keyed on the parameters' autograd version counters (every in-place
+    update bumps them: load_state_dict, broadcast, torch optimisers; srcgan_amd.optim.Adam's native step bumps them
+    explicitly), their addresses and the layout-relevant part of the configuration."""
+
+    def __init__(self):
+        self.buf = None
+        self.fwd_key = None
+        self.bwd_key = None
+
+    @staticmethod
+    def key(params, extra):
+        return (sum(p._version for p in params), params[0].data_ptr(), params[-1].data_ptr(), len(params), extra)
+
+    def opts(self, lib_bytes_fn, cfg, params, extra, backward, device):
+        """-> (NetOpts, keepalive).  Allocates / re-packs as needed."""
+        k = self.key(params, extra)
+        need = int(lib_bytes_fn(C.byref(cfg)))
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device or getattr(self, "layout", None) != extra:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+            self.fwd_key = self.bwd_key = None
+            self.layout = extra
+        if backward:
+            pack = self.bwd_key != k
+            self.bwd_key = k
+        else:
+            pack = self.fwd_key != k
+            self.fwd_key = k
+        return N.NetOpts(self.buf.data_ptr(), int(pack), 0, 0)
+
+
+class _GradArena:
+    """One flat f32 buffer for all parameter gradients a backward call produces; ``views[i]`` aliases it with the parameter's
+    shape.  autograd's AccumulateGrad adopts the views as ``.grad`` (no copy), so the data-parallel all-reduce runs on slices of
+    the flat buffer in place -- no flatten / copy-back passes (srcgan_amd.dist.GradSync)."""
+
+    def __init__(self, params, needs):
+        sizes = [p.numel() if n else 0 for p, n in zip(params, needs)]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=params[0].device)
+        self.views, self.offsets, off = [], [0], 0
+        for p, n, sz in zip(params, needs, sizes):
+            self.views.append(self.flat[off:off + sz].view_as(p) if n else None)
+            off += sz
+            self.offsets.append(off)          # offsets[i] .. offsets[i + 1] = parameter i
+
+
 class _RddbFn(torch.autograd.Function):
     """One native forward / one native backward for the whole generator."""
 
@@ -88,6 +136,7 @@ class _RddbFn(torch.autograd.Function):
         lib = N.lib()
         in_ch, out_ch, up, nf, nb, gc, dtype, down = cfg_items[:8]
         legacy = cfg_items[8] if len(cfg_items) > 8 else 0
+        pstate = cfg_items[9] if len(cfg_items) > 9 else None
         if x.dim() != 4 or x.shape[1] != in_ch:
             raise ValueError(f"RDDBNet expects [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
@@ -108,11 +157,14 @@ class _RddbFn(torch.autograd.Function):
         f = (up if down == 0 else 1)
         HO, WO = (H * f, W * f) if down <= 1 else (H // down, W // down)
         y = torch.empty(B, out_ch, HO, WO, dtype=torch.float32, device=x.device)
-        N.check(lib.srcgan_rddbnet_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(),
-                                           N.stream_ptr(x.device)), "srcgan_rddbnet_forward")
+        layout = (in_ch, out_ch, up, nf, nb, gc, dtype, down, legacy)
+        opt = pstate.opts(lib.srcgan_rddbnet_wpack_bytes, cfg, plist, layout, False, x.device) if pstate is not None else None
+        N.check(lib.srcgan_rddbnet_forward_ex(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(),
+                                              C.byref(opt) if opt is not None else None, N.stream_ptr(x.device)), "srcgan_rddbnet_forward")
         ctx.cfg, ctx.ws, ctx.n = cfg, ws, len(plist)
+        ctx.pstate, ctx.layout = pstate, layout
         ctx.save_for_backward(*plist)
-        ctx.hook = _grad_hooks.get("rddb")
+        ctx.phase_hook = _phase_hooks.get("rddb")
         return y
 
     @staticmethod
@@ -126,22 +178,38 @@ class _RddbFn(torch.autograd.Function):
             raise RuntimeError("RDDBNet backward called twice (activations were released)")
         dy = dy.contiguous().float()
         need_dx = ctx.needs_input_grad[0]
-        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[2 + i] else None
-                                               for i, p in enumerate(params)]
+        arena = _GradArena(params, [ctx.needs_input_grad[2 + i] for i in range(len(params))])
+        grads = arena.views
         scratch = N.workspace(lib.srcgan_rddbnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
-        N.check(lib.srcgan_rddbnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
-                                            scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
-                                            N.stream_ptr(dy.device)), "srcgan_rddbnet_backward")
+        pstate = ctx.pstate
+        opt = pstate.opts(lib.srcgan_rddbnet_wpack_bytes, cfg, params, ctx.layout, True, dy.device) if pstate is not None else N.NetOpts(None, 0, 0, 0)
+        gptr, pptr = N.ptr_array(grads), N.ptr_array(params)
+        hook = ctx.phase_hook
+        nrr = 0 if cfg.legacy == 2 else (2 * cfg.nb if cfg.legacy == 3 else cfg.nb)
+        # phases: RRDB ranges, last to first (one phase unless a data-parallel hook asks for more)
+        cuts = hook.cuts(cfg, nrr) if (hook is not None and nrr > 1) else [0]
+        hi = nrr
+        for lo in sorted(set(cuts) | {0}, reverse=True):
+            if lo >= hi and hi != nrr:
+                continue
+            opt.rrdb_lo, opt.rrdb_hi = (lo, hi) if nrr > 0 else (0, 0)
+            N.check(lib.srcgan_rddbnet_backward_ex(C.byref(cfg), dy.data_ptr(), pptr, ctx.ws.data_ptr(), scratch.data_ptr(), gptr,
+                                                   dx.data_ptr() if need_dx else None, C.byref(opt), N.stream_ptr(dy.device)),
+                    "srcgan_rddbnet_backward")
+            opt.pack = 0
+            if hook is not None:
+                hook.phase_done(arena, params, cfg, lo, hi, nrr)
+            hi = lo
         ctx.ws = None
-        if ctx.hook is not None:
-            ctx.hook(grads)
         return (dx, None, *grads)
 
 
-# optional callbacks run on the freshly computed parameter gradients inside backward
-# (srcgan_amd.dist installs the gradient all-reduce here so it overlaps with the rest of backward)
-_grad_hooks = {}
+# Data-parallel hooks (srcgan_amd.dist.GradSync.attach): an object with ``cuts(nrr) -> [rrdb indices]`` (phase boundaries of the
+# generator's backward) and ``phase_done(arena, params, cfg, lo, hi, nrr)``, called right after the native call that finalised the
+# gradients of RRDBs [lo, hi) (plus the tail when hi == nrr, the head when lo == 0) was queued: the hook launches their all-reduce
+# on its side stream while the next phase computes.
+_phase_hooks = {}
 
 
 class RDDBNet(nn.Module):
@@ -164,12 +232,13 @@ class RDDBNet(nn.Module):
         _kaiming_like_reference(self)
         self._cfg = (in_ch, ou_ch, upscale_factor, nf, nb, gc)
         self.compute_dtype = N.dtype_name(dtype)
+        self._pack = _PackState()
 
     def _down(self):
         return 0
 
     def forward(self, x):
-        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down())
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down(), 0, self._pack)
         # parameters in state_dict order == the order the native planner assumes
         return _RddbFn.apply(x, cfg, *self.parameters())
 
@@ -195,7 +264,7 @@ class RDDBNetA(RDDBNet):
         return max(1, self.down_factor)
 
     def forward(self, x):
-        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down())
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down(), 0, self._pack)
         # native order: conv_first, down_layers, trunk, trunk_conv, conv_last
         ps = [self.conv_first.weight, self.conv_first.bias, *self.down_layers.parameters(),
               *self.RRDB_trunk.parameters(), self.trunk_conv.weight, self.trunk_conv.bias, self.conv_last.weight]
@@ -300,7 +369,6 @@ class _ResDeconvFn(torch.autograd.Function):
                                              N.stream_ptr(x.device)), "srcgan_resdeconv_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(*plist)
-        ctx.hook = _grad_hooks.get("resdeconv")
         return y
 
     @staticmethod
@@ -313,13 +381,14 @@ class _ResDeconvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("ResDeconv: no gradient w.r.t. the input (detach it: the reference harness feeds it data, trainCas.py:99-100,108)")
         dy = dy.contiguous().float()
-        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(params)]
+        arena = _GradArena(params, [ctx.needs_input_grad[3 + i] for i in range(len(params))])
+        grads = arena.views
         scratch = N.workspace(lib.srcgan_resdeconv_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         N.check(lib.srcgan_resdeconv_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
                                               N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_resdeconv_backward")
         ctx.ws = None
-        if ctx.hook is not None:
-            ctx.hook(grads)
+        if _phase_hooks.get("resdeconv") is not None:
+            _phase_hooks["resdeconv"].phase_done(arena, params, cfg, 0, 0, 0)
         return (None, None, None, *grads)
 
 
@@ -419,7 +488,6 @@ class _SrNetFn(torch.autograd.Function):
                 "srcgan_srnet_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(*plist)
-        ctx.hook = _grad_hooks.get("srnet")
         return y
 
     @staticmethod
@@ -432,13 +500,14 @@ class _SrNetFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("ESPCN/SRCNN: no gradient w.r.t. the input (the reference harness feeds data, trainCas.py:89-91)")
         dy = dy.contiguous().float()
-        grads: List[Optional[torch.Tensor]] = [torch.empty_like(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(params)]
+        arena = _GradArena(params, [ctx.needs_input_grad[2 + i] for i in range(len(params))])
+        grads = arena.views
         scratch = N.workspace(lib.srcgan_srnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         N.check(lib.srcgan_srnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
                                           N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_srnet_backward")
         ctx.ws = None
-        if ctx.hook is not None:
-            ctx.hook(grads)
+        if _phase_hooks.get("srnet") is not None:
+            _phase_hooks["srnet"].phase_done(arena, params, cfg, 0, 0, 0)
         return (None, None, *grads)
 
 
@@ -555,7 +624,7 @@ class _NLayerDFn(torch.autograd.Function):
     def forward(ctx, x, cfg_items, running, nbt, *params):
         N.require_cuda(x, "NLayerDiscriminator.forward")
         lib = N.lib()
-        in_ch, ndf, n_layers, dtype, training = cfg_items
+        in_ch, ndf, n_layers, dtype, training, pstate = cfg_items
         if x.dim() != 4 or x.shape[1] != in_ch:
             raise ValueError(f"NLayerDiscriminator expects [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
@@ -566,12 +635,15 @@ class _NLayerDFn(torch.autograd.Function):
         N.check(lib.srcgan_nlayerd_out_hw(C.byref(cfg), C.byref(oh), C.byref(ow)), "srcgan_nlayerd_out_hw")
         ws = N.workspace(lib.srcgan_nlayerd_ws_bytes(C.byref(cfg)), x.device)
         y = torch.empty(B, 1, oh.value, ow.value, dtype=torch.float32, device=x.device)
-        N.check(lib.srcgan_nlayerd_forward(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), N.ptr_array(running),
-                                           N.ptr_array(nbt), ws.data_ptr(), y.data_ptr(), N.stream_ptr(x.device)),
+        layout = (in_ch, ndf, n_layers, dtype, H % 2, W % 2)          # (the first layer's packed form depends on the parity of H, W)
+        opt = pstate.opts(lib.srcgan_nlayerd_wpack_bytes, cfg, plist, layout, False, x.device)
+        N.check(lib.srcgan_nlayerd_forward_ex(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), N.ptr_array(running),
+                                              N.ptr_array(nbt), ws.data_ptr(), y.data_ptr(), C.byref(opt), N.stream_ptr(x.device)),
                 "srcgan_nlayerd_forward")
         ctx.cfg, ctx.ws = cfg, ws
+        ctx.pstate, ctx.layout = pstate, layout
         ctx.save_for_backward(*plist)
-        ctx.hook = _grad_hooks.get("nlayerd")
+        ctx.phase_hook = _phase_hooks.get("nlayerd")
         return y
 
     @staticmethod
@@ -583,15 +655,18 @@ class _NLayerDFn(torch.autograd.Function):
             raise RuntimeError("NLayerDiscriminator backward called twice (activations were released)")
         dy = dy.contiguous().float()
         need_dx = ctx.needs_input_grad[0]
-        grads = [torch.empty_like(p) if ctx.needs_input_grad[4 + i] else None for i, p in enumerate(params)]
+        needs = [ctx.needs_input_grad[4 + i] for i in range(len(params))]
+        arena = _GradArena(params, needs) if any(needs) else None
+        grads = arena.views if arena is not None else [None] * len(params)
         scratch = N.workspace(lib.srcgan_nlayerd_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
-        N.check(lib.srcgan_nlayerd_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
-                                            scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
-                                            N.stream_ptr(dy.device)), "srcgan_nlayerd_backward")
+        opt = ctx.pstate.opts(lib.srcgan_nlayerd_wpack_bytes, cfg, params, ctx.layout, True, dy.device)
+        N.check(lib.srcgan_nlayerd_backward_ex(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
+                                               scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
+                                               C.byref(opt), N.stream_ptr(dy.device)), "srcgan_nlayerd_backward")
         ctx.ws = None
-        if ctx.hook is not None:
-            ctx.hook(grads)
+        if ctx.phase_hook is not None and arena is not None:
+            ctx.phase_hook.phase_done(arena, params, cfg, 0, 0, 0)
         return (dx, None, None, None, *grads)
 
 
@@ -619,12 +694,13 @@ class NLayerDiscriminator(nn.Module):
         self.model = nn.Sequential(*seq)
         self._cfg = (input_nc, ndf, n_layers)
         self.compute_dtype = N.dtype_name(dtype)
+        self._pack = _PackState()
 
     def forward(self, input):
         bns = [m for m in self.model if isinstance(m, nn.BatchNorm2d)]
         running = [t for m in bns for t in (m.running_mean, m.running_var)]
         nbt = [m.num_batches_tracked for m in bns]
-        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self.training)
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self.training, self._pack)
         return _NLayerDFn.apply(input, cfg, running, nbt, *self.parameters())
 
     def extra_repr(self):

@@ -256,6 +256,6 @@ def group_norm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats
     scr = torch.empty(lib.srcgan_gn_scratch_floats(B, Cc), dtype=torch.float32, device=x.device)
     N.check(lib.srcgan_gn_backward(dy.data_ptr(), Cc, yact.data_ptr() if yact is not None else None, Cc, x.data_ptr(), Cc,
                                    gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(), Cc, dres.data_ptr() if want_dres else None, Cc, 0,
-                                   dgamma.data_ptr(), dbeta.data_ptr(), 0, slope, B, H * W, Cc, G, 0, 0, N.dtype_id(x.dtype), scr.data_ptr(),
+                                   dgamma.data_ptr(), dbeta.data_ptr(), 0, slope, B, H * W, Cc, G, N.dtype_id(x.dtype), scr.data_ptr(),
                                    N.stream_ptr(x.device)), "srcgan_gn_backward")
     return dx, dres, dgamma, dbeta

@@ -66,18 +66,29 @@ class Adam(torch.optim.Adam):
                 ent = {"shapes": shapes, "chunks": torch.from_numpy(chunks).to(ps[0].device), "n": int(len(tid)), "ptrs": None,
                        "tensors": torch.empty(len(ps) * 4, dtype=torch.int64, device=ps[0].device),
                        # two pinned staging buffers, used alternately: the upload is asynchronous (a pageable copy would make the
-                       # host wait for the whole backward pass queued on the stream) and at most one step is in flight behind it
-                       "pinned": [torch.empty(len(ps) * 4, dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0}
+                       # host wait for the whole backward pass queued on the stream).  The host may run several steps ahead of the
+                       # device (nothing in a training step synchronises), so each buffer carries the event of its last upload and
+                       # is rewritten only after that copy has executed.
+                       "pinned": [torch.empty(len(ps) * 4, dtype=torch.int64).pin_memory() for _ in range(2)], "events": [None, None], "flip": 0}
                 cache[gi] = ent
             if ent["ptrs"] is None or not np.array_equal(ent["ptrs"], ptrs):      # fresh .grad tensors move between steps
                 ent["ptrs"] = ptrs
-                stage = ent["pinned"][ent["flip"]]
+                f = ent["flip"]
                 ent["flip"] ^= 1
+                stage = ent["pinned"][f]
+                if ent["events"][f] is not None:
+                    ent["events"][f].synchronize()          # the copy that last read this staging buffer has run
                 stage.numpy()[:] = ptrs.view(np.int64).reshape(-1)
                 ent["tensors"].copy_(stage, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(ps[0].device))
+                ent["events"][f] = ev
             b1, b2 = group["betas"]
             N.check(lib.srcgan_adam_step(ent["tensors"].data_ptr(), ent["chunks"].data_ptr(), ent["n"], float(group["lr"]), float(b1), float(b2),
                                          float(group["eps"]), steps.pop(), N.stream_ptr(ps[0].device)), "srcgan_adam_step")
+            # the native kernel wrote the parameters through raw pointers: tell autograd (version counters), as an in-place torch op
+            # would have -- the modules' packed-weight caches are keyed on them (srcgan_amd.model._PackState)
+            torch.autograd.graph.increment_version(ps)
         return loss
 
 

@@ -25,7 +25,7 @@ from .losses import GANLoss, L1Loss, PSNRLoss
 from .model import EDSR, ESPCN, SRCNN, SRDN, NLayerDiscriminator, RDDBNet, RDDBNetA, RDDBNetB, ResDeconv
 from .optim import Adam
 
-__all__ = ["PairedSRGAN", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasSRCConst", "CasSRCLAB", "CasSRCConstLAB", "CasParams",
+__all__ = ["PairedSRGAN", "StackedSR", "SRCycleGAN", "CycleParams", "ImagePool", "CasSRC", "CasSRCConst", "CasSRCLAB", "CasSRCConstLAB", "CasParams",
            "set_requires_grad"]
 
 
@@ -54,14 +54,17 @@ class PairedSRGAN:
         self.lambda_l1 = lambda_l1
         self.optimizer_G = Adam(self.netG.parameters(), lr=lr_g, betas=(beta1, 0.999))      # a torch.optim.Adam with a fused step()
         self.optimizer_D = Adam(self.netD.parameters(), lr=lr_d, betas=(beta1, 0.999))
-        self.grad_sync = None      # srcgan_amd.dist.GradSync (data parallel) or None
+        # Data parallel: srcgan_amd.dist.GradSync.  Attached (``GradSync().attach()``, what bench.py does) it averages the
+        # gradients INSIDE every native backward call, the generator's in phases overlapped with the rest of its backward;
+        # not attached it is applied after each backward (bucketed all-reduce of the .grad tensors).
+        self.grad_sync = None
 
     def _sync(self, params):
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and not self.grad_sync.attached:
             self.grad_sync.allreduce(params)
 
     def optimize_parameters(self, x, y):
-        # ---- generator
+        # ---- generator (train.py:330-333)
         set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
         self.fake = self.netG(x)
@@ -69,24 +72,69 @@ class PairedSRGAN:
         self.loss_L1 = self.criterionL1(self.fake, y)
         self.loss_G = self.loss_G_GAN + self.loss_L1 * self.lambda_l1
         self.loss_G.backward()
-        # Data parallel: the generator's gradient all-reduce runs on the side stream UNDER the discriminator step, which reads
-        # neither the generator's gradients nor its parameters (it sees fake.detach()); optimizer_G.step() therefore moves
-        # behind the discriminator's backward -- same arithmetic, same results as the reference order (train.py:331-340).
-        pending_g = self.grad_sync.begin(self.netG.parameters()) if self.grad_sync is not None else None
-        if self.grad_sync is None:
-            self.optimizer_G.step()
-        # ---- discriminator
+        self._sync(self.netG.parameters())
+        self.optimizer_G.step()
+        # ---- discriminator (train.py:335-340)
         set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
         loss_real = self.criterionGAN(self.netD(y), True)
         loss_fake = self.criterionGAN(self.netD(self.fake.detach()), False)
         self.loss_D = (loss_real + loss_fake) * 0.5
         self.loss_D.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.end(pending_g)
-            self.optimizer_G.step()
         self._sync(self.netD.parameters())
         self.optimizer_D.step()
+
+
+class StackedSR:
+    """BASELINE.json configs[4] ("Sat2Aerx8 stress"): RDDBNet stages stacked end to end (reference rddb.py:85-114, two instances:
+    x4 then x2 by default -- SURVEY.md section 8d restates the configuration), one L1 loss on the final output, one Adam over
+    all stages (trainCas.py:38-41 hyper-parameters).  A later stage's input gradient flows into the earlier stage through
+    autograd (srcgan_rddbnet_backward's dx).
+
+    ``micro_batch``: the batch is processed in slices of that many images whose gradients accumulate before the one optimiser
+    step.  The generator has no cross-sample coupling (no normalisation layers), so this is the same step as the full batch --
+    what it buys is memory: the dense-block activations of a 512x512 trunk are 7.2 GB per image in 16-bit storage, 231 GB for the
+    configuration's 32 images per GPU; 16-image slices need half of that.
+    ``loss_scale``: multiplies the loss before backward and divides the gradients before the step (fp16 storage: gradients below
+    2^-24 would vanish; bf16 and fp32 need none)."""
+
+    def __init__(self, ups=(4, 2), in_ch=3, out_ch=3, nf=64, nb=23, gc=32, dtype=None, device="cuda", lr=1e-4,
+                 micro_batch: Optional[int] = None, loss_scale: float = 1.0):
+        self.device = torch.device(device)
+        self.nets = [RDDBNet(in_ch if i == 0 else out_ch, out_ch, up, nf=nf, nb=nb, gc=gc, dtype=dtype).to(self.device)
+                     for i, up in enumerate(ups)]
+        self.criterion = L1Loss()
+        self.optimizer = Adam(itertools.chain(*[n.parameters() for n in self.nets]), lr=lr)
+        self.micro_batch = micro_batch
+        self.loss_scale = float(loss_scale)
+        self.grad_sync = None
+
+    def parameters(self):
+        return itertools.chain(*[n.parameters() for n in self.nets])
+
+    def forward(self, x):
+        for net in self.nets:
+            x = net(x)
+        return x
+
+    def optimize_parameters(self, x, y):
+        B = x.shape[0]
+        mb = self.micro_batch or B
+        self.optimizer.zero_grad()
+        total = None
+        for i in range(0, B, mb):
+            xs, ys = x[i:i + mb], y[i:i + mb]
+            out = self.forward(xs)
+            loss = self.criterion(out, ys) * (xs.shape[0] / B)
+            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+            total = loss.detach() if total is None else total + loss.detach()
+            del out, loss
+        if self.grad_sync is not None and not self.grad_sync.attached:
+            self.grad_sync.allreduce(self.parameters())
+        if self.loss_scale != 1.0:
+            torch._foreach_mul_([p.grad for p in self.parameters() if p.grad is not None], 1.0 / self.loss_scale)
+        self.optimizer.step()
+        self.loss = total
 
 
 class ImagePool:
@@ -170,7 +218,7 @@ class SRCycleGAN:
     set_requires_grad = staticmethod(set_requires_grad)
 
     def _sync(self, params):
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and not self.grad_sync.attached:
             self.grad_sync.allreduce(params)
 
     def forward(self, realA, realB):                                     # train.py:228-249 (net == '1')

@@ -48,6 +48,25 @@ def _worker(rank, world, port, q):
         cover[b:e] = 1
         dist.all_reduce(cover)
         assert torch.equal(cover, torch.ones(37))
+        # 4. the in-backward form: arena slices of generator phases, reduced in place; together they cover the arena exactly once
+        import types
+        from srcgan_amd.model import _GradArena
+        nb = 5
+        shapes = [(4, 3), (4,)] + [(2, 2)] * (30 * nb) + [(4, 4), (4,), (3, 3), (1, 3)]
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        arena = _GradArena(ps, [True] * len(ps))
+        arena.flat.copy_(torch.arange(arena.flat.numel(), dtype=torch.float32) * (rank + 1))
+        cfg = types.SimpleNamespace(legacy=0, down=0)
+        gs = sd.GradSync(bucket_mb=0.0001, phases=3)
+        cuts = gs.cuts(cfg, nb)
+        assert cuts[0] == 0 and len(cuts) == 3, cuts
+        hi = nb
+        for lo in sorted(cuts, reverse=True):
+            gs.phase_done(arena, ps, cfg, lo, hi, nb)
+            hi = lo
+        want = torch.arange(arena.flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        assert torch.allclose(arena.flat, want), float((arena.flat - want).abs().max())
+        assert gs.stats["calls"] == 1 and gs.stats["phases"] == 3 and gs.stats["bytes"] == arena.flat.numel() * 4, gs.stats
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))

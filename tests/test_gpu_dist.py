@@ -45,7 +45,9 @@ def test_bench_one_rank_through_rccl():
 
 
 def test_grad_sync_one_rank_keeps_the_step_identical():
-    """With one rank the averaged gradient is the gradient: a step through broadcast + GradSync equals a plain step bit for bit."""
+    """With one rank the averaged gradient is the gradient: a step through broadcast + GradSync equals a plain step bit for bit --
+    both forms: applied after each backward, and attached (averaging inside the native backward calls, the generator's backward
+    split into three RRDB-range phases whose arena slices are reduced in place on the side stream through RCCL)."""
     code = r'''
 import torch, sys
 sys.path.insert(0, %r)
@@ -56,20 +58,28 @@ import torch.distributed as dist
 assert dist.is_initialized() and dist.get_backend() == "nccl"
 def run(sync):
     torch.manual_seed(0)
-    m = PairedSRGAN(3, 3, 2, nf=16, nb=1, gc=8, ndf=16, n_layers=3, dtype="fp32", device="cuda")
+    m = PairedSRGAN(3, 3, 2, nf=16, nb=5, gc=8, ndf=16, n_layers=3, dtype="fp32", device="cuda")
     if sync:
         sdist.broadcast_module(m.netG); sdist.broadcast_module(m.netD)
-        m.grad_sync = sdist.GradSync(bucket_mb=0.05)          # several buckets
+        m.grad_sync = sdist.GradSync(bucket_mb=0.05, phases=3)          # several buckets, three backward phases
         assert m.grad_sync._active
+        if sync == "attached":
+            m.grad_sync.attach()
     g = torch.Generator().manual_seed(5)
     x, y = torch.rand(2, 3, 32, 32, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda()
     for _ in range(2):
         m.optimize_parameters(x, y)
     torch.cuda.synchronize()
+    if sync == "attached":
+        st = m.grad_sync.stats
+        # per step: one generator backward in 3 phases + two discriminator backward calls with parameter gradients
+        assert st["calls"] == 2 * 3 and st["phases"] == 2 * (3 + 2), st
+        m.grad_sync.detach()
     return [p.detach().clone() for p in list(m.netG.parameters()) + list(m.netD.parameters())], float(m.loss_G), float(m.loss_D)
-a, b = run(False), run(True)
-assert a[1] == b[1] and a[2] == b[2], (a[1:], b[1:])
+a, b, c = run(False), run(True), run("attached")
+assert a[1] == b[1] == c[1] and a[2] == b[2] == c[2], (a[1:], b[1:], c[1:])
 assert all(torch.equal(p, q) for p, q in zip(a[0], b[0]))
+assert all(torch.equal(p, q) for p, q in zip(a[0], c[0]))          # phased backward + in-place reduce: bit for bit the plain step
 dist.barrier(); dist.destroy_process_group()
 print("ok")
 ''' % ROOT
@@ -114,3 +124,57 @@ def test_bench_gpus2_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
     assert line["config"]["parallelism"] == "dp2" and line["cpu_baseline"] is None
+
+
+def test_two_ranks_attached_sync_gives_the_mean_gradient():
+    """world_size 2 on the one device (gloo): every rank runs a generator + frozen-discriminator backward on ITS batch with
+    GradSync attached (3 phases); the gradients that reach .grad must be the mean of the two ranks' gradients, which each rank
+    also computes locally without any collective (both batches are seeded)."""
+    code = r'''
+import torch, sys, os
+sys.path.insert(0, %r)
+from srcgan_amd import dist as sdist
+from srcgan_amd.train import PairedSRGAN, set_requires_grad
+rank, local, world = sdist.init_from_env()
+import torch.distributed as dist
+assert world == 2 and dist.get_backend() == "gloo"
+def batch(r):
+    g = torch.Generator().manual_seed(5 + r)
+    return torch.rand(2, 3, 32, 32, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda()
+def grads(m, xs):
+    for p in list(m.netG.parameters()) + list(m.netD.parameters()): p.grad = None
+    for x, y in xs:
+        # generator step's backward (discriminator frozen) ...
+        set_requires_grad(m.netD, False)
+        fake = m.netG(x)
+        (m.criterionGAN(m.netD(fake), True) + m.criterionL1(fake, y) * 10.0).backward()
+        # ... and the discriminator step's (two calls with parameter gradients)
+        set_requires_grad(m.netD, True)
+        ((m.criterionGAN(m.netD(y), True) + m.criterionGAN(m.netD(fake.detach()), False)) * 0.5).backward()
+    torch.cuda.synchronize()
+    return [p.grad.detach().clone() for p in list(m.netG.parameters()) + list(m.netD.parameters())]
+torch.manual_seed(0)
+m = PairedSRGAN(3, 3, 2, nf=16, nb=4, gc=8, ndf=16, n_layers=2, dtype="fp32", device="cuda")
+m.netD.eval(); m.netD.train()
+ref = [g / 2 for g in grads(m, [batch(0), batch(1)])]          # sum over both ranks' batches / world, no collective
+for bn in [mod for mod in m.netD.modules() if isinstance(mod, torch.nn.BatchNorm2d)]:
+    bn.reset_running_stats()
+sync = sdist.GradSync(bucket_mb=0.05, phases=3).attach()
+got = grads(m, [batch(rank)])
+sync.detach()
+worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-20)) for a, b in zip(got, ref))
+assert worst < 1e-5, worst
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    env = dict(os.environ)
+    env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SRCGAN_FORCE_DIST"):
+        env.pop(k, None)
+    script = os.path.join(ROOT, "gpurun_out", "_dp_mean_test.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, "w") as f:
+        f.write(code)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), script], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.count("ok") == 2, (out.stdout[-500:], out.stderr[-3000:])

@@ -144,6 +144,38 @@ def test_cycle_step_with_reference_g_a_vs_oracle():
         assert rel_err(v.cpu(), st.ga[k].detach()) < 2e-3, k
 
 
+def test_fused_adam_host_running_ahead_with_moving_grads():
+    """The training step never synchronises, so the host can queue several optimiser steps while the device is still busy.  Every
+    step here sees FRESH .grad tensors (new addresses -> a new pointer table upload through the two pinned staging buffers); the
+    device is kept busy so that >= 6 uploads are queued before the first one runs.  A staging buffer rewritten before its copy
+    has executed would make an earlier step use a later step's pointers: compare with torch.optim.Adam."""
+    from srcgan_amd.optim import Adam
+    torch.manual_seed(9)
+    shapes = [(64, 32, 3, 3), (64,), (7,), (3000,)]
+    pa = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = Adam(pa, lr=1e-2, betas=(0.5, 0.999)), torch.optim.Adam(pb, lr=1e-2, betas=(0.5, 0.999), foreach=False)
+    nsteps = 8
+    gs = [[torch.randn(s, device="cuda") for s in shapes] for _ in range(nsteps)]
+    keep = []                                          # hold every grad tensor: the allocator must hand out new addresses
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(30):                                # ~100 ms of queued device work: the host runs ahead of it
+        big = (big @ big).clamp_(-1, 1)
+    for step in range(nsteps):
+        for a, g in zip(pa, gs[step]):
+            a.grad = g.clone()
+            keep.append(a.grad)
+        oa.step()
+    for step in range(nsteps):
+        for b, g in zip(pb, gs[step]):
+            b.grad = g.clone()
+        ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
+
+
 def test_fused_adam_matches_torch_adam():
     """srcgan_amd.optim.Adam (one native launch per group) against torch.optim.Adam over several steps, both beta1 settings the
     reference uses (0.9 default, 0.5 for the GAN), odd sizes; state_dict interchange; fallback for unsupported options."""
