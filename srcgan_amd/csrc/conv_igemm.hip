@@ -76,42 +76,54 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         const bool ok = pc < NPH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         h_goff[it] = ok ? ((gy * p.W + gx) * (int)p.xpix + part * 16) : -1;
     }
-    u32x4 hreg[HIT];
-    u32x4 wreg[WPK ? 1 : WIT];
-    auto issue_halo = [&](int c) {
+    // Two register stages (NRS == 2, kernels with few taps): the loads of chunk c + 2 are issued while chunk c computes.  With one
+    // stage a chunk's loads have only that chunk's MFMA phase to land in -- 32 MFMAs per wave for a 2x2 kernel, ~1000 cycles
+    // against 1500-2500 of load latency -- and the stride-2 parity gradients ran at 0.4 PFLOP/s (4x4 s1, 128 MFMAs: 1.05).
+    // (measured on the stride-2 parity gradients, 2x2 taps: 1.445 -> 1.408 ms per discriminator pass with NRS = 2 -- the loads'
+    //  latency is not what bounds them.  Each parity launch moves ~445 MB for 69 GFLOP (154 FLOP/B): they are close to memory-
+    //  bound as four separate launches; one kernel producing all four parities from one staged dy tile would need a third of the
+    //  traffic -- DESIGN.md section 8.)  Kept switchable; the default is one stage (36 fewer VGPRs).
+    constexpr int NRS = 1;
+    u32x4 hreg[NRS][HIT];
+    u32x4 wreg[NRS][WPK ? 1 : WIT];
+    auto issue_halo = [&](int c, auto rs) {
+        constexpr int R = decltype(rs)::value;
         const bool cok = c * D::KCE + part * D::EPP < p.Cin;
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
             const int off = (h_goff[it] >= 0 && cok) ? h_goff[it] + c * 64 : 0;
-            hreg[it] = *(const u32x4*)(xb + off);
+            hreg[R][it] = *(const u32x4*)(xb + off);
         }
     };
-    auto write_halo = [&](int c) {
+    auto write_halo = [&](int c, auto rs) {
+        constexpr int R = decltype(rs)::value;
         const bool cok = c * D::KCE + part * D::EPP < p.Cin;
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
             const int pc = it * 256 + tid;
-            u32x4 v = hreg[it];
+            u32x4 v = hreg[R][it];
             if (!(h_goff[it] >= 0 && cok)) v = u32x4{0u, 0u, 0u, 0u};
             if (HIT * 256 == NPH || pc < NPH) *(u32x4*)(lds_h + (pc >> 2) * PIXB + part * 16) = v;
         }
     };
-    auto issue_w = [&](int c) {
+    auto issue_w = [&](int c, auto rs) {
+        constexpr int R = decltype(rs)::value;
         if constexpr (!WPK) {
             const char* ws = wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int pc = it * 256 + tid;
-                wreg[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
+                wreg[R][it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
             }
         }
     };
-    auto write_w = [&]() {
+    auto write_w = [&](auto rs) {
+        constexpr int R = decltype(rs)::value;
         if constexpr (!WPK) {
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int pc = it * 256 + tid;
-                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wreg[it];
+                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wreg[R][it];
             }
         }
     };
@@ -140,18 +152,17 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         }
     };
 
-    issue_halo(0);
-    issue_w(0);
-    issue_wrow(0, 0);
-    for (int c = 0; c < p.nchunk; ++c) {
-        // registers (chunk c) -> LDS; the previous chunk's readers passed the barrier at the loop bottom
-        write_halo(c);
-        write_w();
+    using RS0 = std::integral_constant<int, 0>;
+    using RS1 = std::integral_constant<int, NRS - 1>;
+    auto chunk = [&](int c, auto rs) {
+        // registers (chunk c) -> LDS; the previous chunk's readers passed the barrier at the end of the previous call
+        write_halo(c, rs);
+        write_w(rs);
         write_wrow();                 // kernel row 0 of this chunk
         __syncthreads();
-        if (c + 1 < p.nchunk) {       // prefetch the next chunk: in flight while this chunk's MFMAs run
-            issue_halo(c + 1);
-            issue_w(c + 1);
+        if (c + NRS < p.nchunk) {     // prefetch into the registers just drained: in flight while NRS chunks' MFMAs run
+            issue_halo(c + NRS, rs);
+            issue_w(c + NRS, rs);
         }
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
@@ -203,9 +214,32 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
             }
         }
         __syncthreads();   // all waves are done reading this chunk's LDS image
+    };
+    issue_halo(0, RS0{});
+    issue_w(0, RS0{});
+    issue_wrow(0, 0);
+    if constexpr (NRS == 2) {
+        if (p.nchunk > 1) { issue_halo(1, RS1{}); issue_w(1, RS1{}); }
+        for (int c = 0; c < p.nchunk; c += 2) {
+            chunk(c, RS0{});
+            if (c + 1 < p.nchunk) chunk(c + 1, RS1{});
+        }
+    } else {
+        for (int c = 0; c < p.nchunk; ++c) chunk(c, RS0{});
     }
 
-    conv_epilogue<T, MT, PT>(p, acc, b, ct, oy0 + wave * PT, ox0, r, h);
+    // Epilogue.  The MFMA result holds one pixel per lane and 4 channels per register group: stored as it stands every
+    // instruction scatters 8-byte pieces over 32 pixels (a strided parity store of a stride-2 gradient wrote 16 contiguous bytes
+    // per pixel: those convolutions ran at 380 TFLOP/s, store-bound).  With 16-byte-aligned operands each wave transposes a
+    // row of its tile through LDS (the stage buffers are free: every wave passed the loop's last barrier) and reads it back
+    // with the lanes of a pixel contiguous: 128-byte segments per pixel for residual / mask loads and the store.
+    if (p.vec16) {
+        constexpr int RS = COT * 4 + 16;
+        char* lw = smem + wave * 32 * RS;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) conv_epilogue_lds_row<T, MT, PT>(p, acc, q, lw, b, ct, oy0 + wave * PT + q, ox0, lane);
+    } else
+        conv_epilogue<T, MT, PT>(p, acc, b, ct, oy0 + wave * PT, ox0, r, h);
 }
 
 // ------------------------------------------------------------------ host launcher
@@ -214,7 +248,8 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int TH = 4 * PT, TW = 32;
     constexpr int IHT = (TH - 1) * S + KH, IWT = (TW - 1) * S + KW;
     constexpr int COT = 32 * MT, NTAP = KH * KW;
-    constexpr size_t SMEM = (size_t)IHT * IWT * 80 + (size_t)(WPK ? KW : NTAP) * COT * 80;
+    constexpr size_t STAGE = (size_t)IHT * IWT * 80 + (size_t)(WPK ? KW : NTAP) * COT * 80, EPI = (size_t)4 * 32 * (COT * 4 + 16);
+    constexpr size_t SMEM = STAGE > EPI ? STAGE : EPI;       // the LDS-transposed epilogue reuses the stage buffers
     static bool attr_set = false;
     auto kern = conv_igemm_k<T, KH, KW, S, MT, PT, WPK>;
     if (!attr_set) {
@@ -245,7 +280,10 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
     SG_CASE(3, 3, 1, 2, false)
     SG_CASE(1, 1, 1, 2, false)
     SG_CASE(2, 2, 2, 1, false)
-    SG_CASE(2, 2, 1, 2, false)
+#ifndef SG_PT22
+#define SG_PT22 2
+#endif
+    SG_CASE(2, 2, 1, SG_PT22, false)
     SG_CASE(1, 2, 1, 2, false)
     SG_CASE(2, 1, 1, 2, false)
     SG_CASE(4, 4, 2, 1, true)
@@ -320,6 +358,11 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);
         return dispatch_shape<__bf16, 1>(p, d->kh, d->kw, d->stride, 1, st);
     }
+#ifdef SG_MT4_22
+    // (variant) stride-2 parity gradients with >= 128 output rows: one 128-row tile per workgroup halves the dy staging per FLOP
+    if (d->dtype == SRCGAN_BF16 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)
+        return launch_igemm<__bf16, 2, 2, 1, 4, SG_PT22, false>(p, d->Cout / 128, st);
+#endif
     const int ctiles = cdiv(d->Cout, 64);
     if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
     return dispatch_shape<__bf16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
