@@ -14,8 +14,9 @@
  *     (`cs`, elements per pixel) and channel offset (`coff`) so a convolution
  *     can read a channel prefix of a dense-block buffer and write its own
  *     channel slice -- this is what removes torch.cat (rddb.py:64-67).
- *   - dtype: SRCGAN_F32 (exact f32 MFMA, parity mode) or SRCGAN_BF16 (bf16
- *     storage + bf16 MFMA, f32 accumulate; perf mode).
+ *   - dtype: SRCGAN_F32 (exact f32 MFMA, parity mode), SRCGAN_BF16 (bf16
+ *     storage + bf16 MFMA, f32 accumulate; perf mode) or SRCGAN_F16 (the same
+ *     kernels on IEEE half).
  *   - return value: 0 on success, non-zero on error; srcgan_last_error() gives
  *     the message (thread-local).  Shape/alignment violations are rejected on
  *     the host before any launch.
@@ -32,6 +33,8 @@ extern "C" {
 
 #define SRCGAN_F32 0
 #define SRCGAN_BF16 1
+#define SRCGAN_F16 2        /* IEEE half storage + f16 MFMA (same rate as bf16), f32 accumulate: 3 more mantissa bits than bf16, 5-bit exponent
+                               (BASELINE.json configs[4]); gradients below 2^-24 vanish, so training harnesses scale the loss */
 
 int srcgan_version(void);
 const char* srcgan_last_error(void);

@@ -15,9 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SRCGAN_AMD_LIB: developer override used by the kernel-variant experiments in scripts/ (A/B builds side by side)
 LIB_PATH = os.environ.get("SRCGAN_AMD_LIB") or os.path.join(_HERE, "lib", "libsrcgan_amd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 _DTYPES = {"fp32": F32, "f32": F32, "float32": F32, torch.float32: F32,
-           "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16, F32: F32, BF16: BF16}
+           "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16,
+           "fp16": F16, "f16": F16, "float16": F16, "half": F16, torch.float16: F16, F32: F32, BF16: BF16, F16: F16}
 _default_dtype = _DTYPES[os.environ.get("SRCGAN_AMD_DTYPE", "fp32")]
 
 
@@ -27,16 +28,16 @@ def dtype_id(d) -> int:
     try:
         return _DTYPES[d]
     except KeyError:
-        raise ValueError(f"unsupported compute dtype {d!r} (use 'fp32' or 'bf16')") from None
+        raise ValueError(f"unsupported compute dtype {d!r} (use 'fp32', 'bf16' or 'fp16')") from None
 
 
 def dtype_name(d) -> str:
-    return "bf16" if dtype_id(d) == BF16 else "fp32"
+    return {F32: "fp32", BF16: "bf16", F16: "fp16"}[dtype_id(d)]
 
 
 def set_default_dtype(d) -> None:
     """Compute dtype of modules built afterwards: 'fp32' (exact f32 MFMA, parity mode,
-    the default) or 'bf16' (bf16 storage + MFMA, f32 accumulate; perf mode)."""
+    the default), 'bf16' (bf16 storage + MFMA, f32 accumulate; perf mode) or 'fp16' (the same on IEEE half)."""
     global _default_dtype
     _default_dtype = _DTYPES[d]
 

@@ -8,6 +8,8 @@
 #include "../../include/srcgan_amd.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -19,12 +21,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <typename T> struct DT;
 template <> struct DT<float>  { static constexpr int id = SRCGAN_F32;  static constexpr int EPP = 4; static constexpr int KCE = 16; };
 template <> struct DT<__bf16> { static constexpr int id = SRCGAN_BF16; static constexpr int EPP = 8; static constexpr int KCE = 32; };
+template <> struct DT<_Float16> { static constexpr int id = SRCGAN_F16; static constexpr int EPP = 8; static constexpr int KCE = 32; };
+static inline bool sg_is16(int dtype) { return dtype == SRCGAN_BF16 || dtype == SRCGAN_F16; }
+static inline bool sg_dtype_ok(int dtype) { return dtype == SRCGAN_F32 || sg_is16(dtype); }
 
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 from_f<_Float16>(float v) { return (_Float16)v; }
 
 // 4 consecutive channels <-> f32 registers (8-byte bf16 / 16-byte f32 accesses)
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -34,12 +41,35 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float (
 template <> __device__ __forceinline__ void load4<__bf16>(const __bf16* p, float (&v)[4]) {
     bf16x4 t = *(const bf16x4*)p; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
+template <> __device__ __forceinline__ void load4<_Float16>(const _Float16* p, float (&v)[4]) {
+    f16x4 t = *(const f16x4*)p; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
     f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = t;
 }
 template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const float (&v)[4]) {
     bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; *(bf16x4*)p = t;
+}
+
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, const float (&v)[4]) {
+    f16x4 t = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(f16x4*)p = t;
+}
+// 32x32x16 MFMA on 16-byte fragments of a 16-bit type.  Fragments travel as bf16x8 (a 16-byte container: LDS reads do not care);
+// the element type selects the instruction (bf16 and f16 run at the same rate).
+template <typename T> __device__ __forceinline__ f32x16 sg_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16))
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// eight copies of 1.0 in T, as a fragment (bias gradients: a pseudo-tap whose B operand is all ones)
+template <typename T> __device__ __forceinline__ bf16x8 sg_ones16() {
+    typedef __attribute__((ext_vector_type(8))) T v8;
+    v8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)1.0f;
+    return __builtin_bit_cast(bf16x8, o);
 }
 
 // ---------------------------------------------------------------- host side

@@ -175,7 +175,7 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int q = 0; q < PT; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][m], fb[s & 1][q], acc[m][q], 0, 0, 0);
+                            acc[m][q] = sg_mfma16<T>(fa[s & 1][m], fb[s & 1][q], acc[m][q]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #ifdef SG_EXP_NO_MFMA_INSTR    // timing experiment: fragment reads kept alive, no MFMA instructions
                             asm volatile("" :: "v"(fa[ta][m]), "v"(fb[G % NRB]));
 #else
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta][m], fb[G % NRB], acc[m][q], 0, 0, 0);
+                            acc[m][q] = sg_mfma16<T>(fa[ta][m], fb[G % NRB], acc[m][q]);
 #endif
                         }
                     }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         }
         if constexpr (DIRECT) {
             if (direct_ok) {
-                if (!SG_DBG(p, 4)) conv_epilogue_direct32<PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+                if (!SG_DBG(p, 4)) conv_epilogue_direct32<T, PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
                 continue;
             }
         }
@@ -547,7 +547,7 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -614,7 +614,7 @@ static int launch_dma(const ConvP& p, int ctiles, hipStream_t st) {
     if (nwg > nunits) nwg = nunits;
     dim3 grid((unsigned)nwg, 1, 1);
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_dma<%s,MT%d,W%d+%d,PT%d>", sizeof(T) == 4 ? "f32" : "bf16", MT, NWV, NLW, PT);
+    snprintf(cls, sizeof(cls), "conv3x3_dma<%s,MT%d,W%d+%d,PT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, NWV, NLW, PT);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
     hipLaunchKernelGGL(kern, grid, dim3((NWV + NLW) * 64), SMEM, st, q);
@@ -682,5 +682,7 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
 
 // entry used by srcgan_conv_igemm for kh == kw == 3, stride 1
 int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st) {
-    return dtype == SRCGAN_F32 ? dispatch_dma<float>(p, st) : dispatch_dma<__bf16>(p, st);
+    if (dtype == SRCGAN_F32) return dispatch_dma<float>(p, st);
+    if (dtype == SRCGAN_F16) return dispatch_dma<_Float16>(p, st);
+    return dispatch_dma<__bf16>(p, st);
 }

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
                             for (int q = 0; q < PT; ++q)
-                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bb[q], acc[m][q], 0, 0, 0);
+                                acc[m][q] = sg_mfma16<T>(a[m], bb[q], acc[m][q]);
                     }
                 }
             }
@@ -262,7 +262,7 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     q.ctiles = ctiles;
     dim3 grid((unsigned)((size_t)q.tiles_x * q.tiles_y * p.B * ctiles), 1, 1);
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv_igemm<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", KH, KW, S, MT);
+    snprintf(cls, sizeof(cls), "conv_igemm<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), KH, KW, S, MT);
     // algorithmic work: 2*pixels*taps*Cin*Cout flop; bytes: input read once + output written once
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * NTAP * p.Cin * p.Cout,
@@ -302,7 +302,7 @@ static const bool g_force_generic = sg_env("SRCGAN_GENERIC_3X3") != nullptr;   /
 
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     SG_REQUIRE(d && d->x && d->wp && d->y, "srcgan_conv_igemm: null pointer");
-    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_igemm: bad dtype %d", d->dtype);
+    SG_REQUIRE(sg_dtype_ok(d->dtype), "srcgan_conv_igemm: bad dtype %d", d->dtype);
     const int esz = d->dtype == SRCGAN_F32 ? 4 : 2;
     const int epp = 16 / esz;
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0,
@@ -331,7 +331,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.rev = d->rev_batch;
     p.sgn_out = (unsigned char*)d->sign_out; p.sgn_in = (const unsigned char*)d->sign_in;
     if (d->sign_out || d->sign_in)
-        SG_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dtype == SRCGAN_BF16 && d->Cout == 32 && d->os == 1 && d->oa == 0 && d->ob == 0 &&
+        SG_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && sg_is16(d->dtype) && d->Cout == 32 && d->os == 1 && d->oa == 0 && d->ob == 0 &&
                    d->YH == d->OH && d->YW == d->OW && d->x_plane && !(d->sign_in && d->mz) && (!d->sign_out || d->act),
                    "srcgan_conv_igemm: sign masks need a 3x3 s1 bf16 conv with Cout == 32 on a blocked input, unscaled output (and act for sign_out, no mz beside sign_in)");
     p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
@@ -356,14 +356,16 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
         if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);
+        if (d->dtype == SRCGAN_F16) return dispatch_shape<_Float16, 1>(p, d->kh, d->kw, d->stride, 1, st);
         return dispatch_shape<__bf16, 1>(p, d->kh, d->kw, d->stride, 1, st);
     }
 #ifdef SG_MT4_22
     // (variant) stride-2 parity gradients with >= 128 output rows: one 128-row tile per workgroup halves the dy staging per FLOP
-    if (d->dtype == SRCGAN_BF16 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)
+    if (sg_is16(d->dtype) && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)
         return launch_igemm<__bf16, 2, 2, 1, 4, SG_PT22, false>(p, d->Cout / 128, st);
 #endif
     const int ctiles = cdiv(d->Cout, 64);
     if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
+    if (d->dtype == SRCGAN_F16) return dispatch_shape<_Float16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
     return dispatch_shape<__bf16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
 }

@@ -387,10 +387,10 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 // scratch is a stage buffer); this one is ~150 VALU instructions per wave and needs no barrier, so a wave goes from its last
 // MFMA straight to its stores.  Bias comes from the LDS copy; the sign mask word of a pixel is read by both of its lanes, and
 // written by the h == 0 lane after a cross-half exchange.
-template <int PT, int EM>
+template <typename T, int PT, int EM>
 __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32x16 (&acc)[1][PT], const char* lds_bias,
                                                        int b, int oy0, int ox0, int lane) {
-    using T = __bf16;
+    typedef __attribute__((ext_vector_type(4))) T vec4T;
     const int r = lane & 31, h = lane >> 5;
     const int ox = ox0 + r;
     const bool xok = ox < p.OW;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
         unsigned mine = 0u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bf16x4 o;
+            vec4T o;
             const f32x4 bias = *(const f32x4*)(lds_bias + (8 * g + 4 * h) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -425,7 +425,7 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
                 if (EM & 16) mine |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + i);
                 o[i] = from_f<T>(v);
             }
-            if (xok && !SG_DBG(p, 32)) *(bf16x4*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
+            if (xok && !SG_DBG(p, 32)) *(vec4T*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
             if (SG_DBG(p, 32)) asm volatile("" :: "v"(o));
         }
         if (EM & 16) {

@@ -191,14 +191,12 @@ __global__ __launch_bounds__((NCW + (BIASW ? 1 : 0)) * 64) void conv_wgrad_k(con
                             const bf16x8 bv = tr_frag(base, base + 4 * S * PB);
 #pragma unroll
                             for (int m = 0; m < MT; ++m)
-                                acc[tl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[tl][m], 0, 0, 0);
+                                acc[tl][m] = sg_mfma16<T>(a[m], bv, acc[tl][m]);
                         }
                     }
                 }
             } else if (do_bias) {
-                bf16x8 ones;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+                const bf16x8 ones = sg_ones16<T>();
 #pragma unroll 2
                 for (int kk = 0; kk < TH * 2; ++kk) {
                     const int py = kk >> 1, xh = (kk & 1) * 16;
@@ -206,7 +204,7 @@ __global__ __launch_bounds__((NCW + (BIASW ? 1 : 0)) * 64) void conv_wgrad_k(con
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const char* base = lds_d + (m * TH * TW + py * TW + px0) * PB + choff;
-                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(base, base + 4 * PB), ones, acc[0][m], 0, 0, 0);
+                        acc[0][m] = sg_mfma16<T>(tr_frag(base, base + 4 * PB), ones, acc[0][m]);
                     }
                 }
             }
@@ -319,7 +317,7 @@ static int launch_wgrad(WgradP p, hipStream_t st) {
     if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
     dim3 grid((unsigned)p.citiles, (unsigned)p.ctiles, (unsigned)p.nsplit);
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv_wgrad<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : "bf16", KH, KW, S, MT);
+    snprintf(cls, sizeof(cls), "conv_wgrad<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), KH, KW, S, MT);
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * KH * KW * p.Cin * p.Cout,
                                   ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
@@ -353,7 +351,7 @@ static int dispatch_wgrad(const WgradP& p, int kh, int kw, int s, hipStream_t st
 extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     SG_REQUIRE(d && d->dy && d->x && d->slab && d->grad, "srcgan_conv_wgrad: null pointer");
     SG_REQUIRE(!d->bias_grad || (d->kh == 3 && d->kw == 3), "srcgan_conv_wgrad: fused bias gradient is implemented for 3x3 kernels only");
-    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_conv_wgrad: bad dtype %d", d->dtype);
+    SG_REQUIRE(sg_dtype_ok(d->dtype), "srcgan_conv_wgrad: bad dtype %d", d->dtype);
     const int esz = d->dtype == SRCGAN_F32 ? 4 : 2, epp = 16 / esz;
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0 && d->nsplit > 0,
                "srcgan_conv_wgrad: non-positive dimension");
@@ -378,8 +376,10 @@ extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (cot == 32) rc = d->dtype == SRCGAN_F32 ? dispatch_wgrad<float, 1>(p, d->kh, d->kw, d->stride, st)
+                      : d->dtype == SRCGAN_F16 ? dispatch_wgrad<_Float16, 1>(p, d->kh, d->kw, d->stride, st)
                                                : dispatch_wgrad<__bf16, 1>(p, d->kh, d->kw, d->stride, st);
     else rc = d->dtype == SRCGAN_F32 ? dispatch_wgrad<float, 2>(p, d->kh, d->kw, d->stride, st)
+            : d->dtype == SRCGAN_F16 ? dispatch_wgrad<_Float16, 2>(p, d->kh, d->kw, d->stride, st)
                                      : dispatch_wgrad<__bf16, 2>(p, d->kh, d->kw, d->stride, st);
     if (rc) return rc;
     WredP q;

@@ -11,7 +11,7 @@ void srcgan_set_error(const char* fmt, ...) {
 }
 extern "C" const char* srcgan_last_error(void) { return g_err; }
 extern "C" int srcgan_version(void) { return 100; }
-extern "C" int srcgan_dtype_size(int dtype) { return dtype == SRCGAN_F32 ? 4 : (dtype == SRCGAN_BF16 ? 2 : 0); }
+extern "C" int srcgan_dtype_size(int dtype) { return dtype == SRCGAN_F32 ? 4 : (sg_is16(dtype) ? 2 : 0); }
 
 // --------------------------------------------------------------------------- launch profiling
 #include <vector>
@@ -65,6 +65,7 @@ extern "C" int srcgan_prof_get(int i, const char** cls, long* count, double* ms,
 #define DISPATCH_DTYPE(dtype, ...) \
     if ((dtype) == SRCGAN_F32) { using T = float; __VA_ARGS__; } \
     else if ((dtype) == SRCGAN_BF16) { using T = __bf16; __VA_ARGS__; } \
+    else if ((dtype) == SRCGAN_F16) { using T = _Float16; __VA_ARGS__; } \
     else SG_FAIL("bad dtype %d", (int)(dtype));
 
 static inline int ew_blocks(long n, int per_block = 256) {
@@ -131,8 +132,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src,
 
 // Image-channel fast paths (C <= 8 channels in 8-channel bf16 records, HW % 4 == 0): a thread moves 4 consecutive
 // pixels -- one float4 per plane on the NCHW side, 4 x 16 B = 64 contiguous bytes on the NHWC side.
-__global__ __launch_bounds__(256) void nchw_to_nhwc8_k(const float* __restrict__ src, __bf16* __restrict__ dst, int C, long HW, long nquad) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 rec8;
+template <typename T16>
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_k(const float* __restrict__ src, T16* __restrict__ dst, int C, long HW, long nquad) {
+    typedef __attribute__((ext_vector_type(8))) T16 rec8;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
         const long b = q / (HW / 4), p0 = (q % (HW / 4)) * 4;
         float4 v[8];
@@ -141,15 +143,16 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc8_k(const float* __restrict__
             v[c] = c < C ? *(const float4*)(src + ((size_t)b * C + c) * HW + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
         rec8 r[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { r[0][c] = from_f<__bf16>(v[c].x); r[1][c] = from_f<__bf16>(v[c].y); r[2][c] = from_f<__bf16>(v[c].z); r[3][c] = from_f<__bf16>(v[c].w); }
+        for (int c = 0; c < 8; ++c) { r[0][c] = from_f<T16>(v[c].x); r[1][c] = from_f<T16>(v[c].y); r[2][c] = from_f<T16>(v[c].z); r[3][c] = from_f<T16>(v[c].w); }
         rec8* o = (rec8*)(dst + ((size_t)b * HW + p0) * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = r[j];
     }
 }
 
-__global__ __launch_bounds__(256) void nhwc8_to_nchw_k(const __bf16* __restrict__ src, float* __restrict__ dst, int C, long HW, long nquad) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 rec8;
+template <typename T16>
+__global__ __launch_bounds__(256) void nhwc8_to_nchw_k(const T16* __restrict__ src, float* __restrict__ dst, int C, long HW, long nquad) {
+    typedef __attribute__((ext_vector_type(8))) T16 rec8;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
         const long b = q / (HW / 4), p0 = (q % (HW / 4)) * 4;
         const rec8* in = (const rec8*)(src + ((size_t)b * HW + p0) * 8);
@@ -254,9 +257,10 @@ extern "C" int srcgan_s2d_wgrad_unfold(const float* gfold, float* grad, int Cout
 extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cs, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "srcgan_nchw_f32_to_nhwc: bad arguments");
     const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
-    if (dtype == SRCGAN_BF16 && cs == 8 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+    if (sg_is16(dtype) && cs == 8 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
         const long nq = (long)B * (HW / 4);
-        hipLaunchKernelGGL(nchw_to_nhwc8_k, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, C, HW, nq);
+        if (dtype == SRCGAN_F16) hipLaunchKernelGGL(nchw_to_nhwc8_k<_Float16>, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, C, HW, nq);
+        else hipLaunchKernelGGL(nchw_to_nhwc8_k<__bf16>, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, C, HW, nq);
         SG_LAUNCH_CHECK();
         return 0;
     }
@@ -269,9 +273,10 @@ extern "C" int srcgan_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C
 extern "C" int srcgan_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int cs, int coff, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && cs >= C + coff, "srcgan_nhwc_to_nchw_f32: bad arguments");
     const long HW = (long)H * W, np = (long)B * cdivl(HW, 64);
-    if (dtype == SRCGAN_BF16 && cs == 8 && coff == 0 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+    if (sg_is16(dtype) && cs == 8 && coff == 0 && HW % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
         const long nq = (long)B * (HW / 4);
-        hipLaunchKernelGGL(nhwc8_to_nchw_k, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst, C, HW, nq);
+        if (dtype == SRCGAN_F16) hipLaunchKernelGGL(nhwc8_to_nchw_k<_Float16>, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, C, HW, nq);
+        else hipLaunchKernelGGL(nhwc8_to_nchw_k<__bf16>, dim3(ew_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst, C, HW, nq);
         SG_LAUNCH_CHECK();
         return 0;
     }
@@ -856,28 +861,22 @@ __global__ __launch_bounds__(256) void sum2x2_nhwc_k(const T* __restrict__ src, 
 extern "C" int srcgan_upsample2_nhwc(const void* src, int s_cs, int s_coff, long s_plane, void* dst, int d_cs,
                                      int B, int H, int W, int C, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "srcgan_upsample2_nhwc: bad arguments");
-    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "srcgan_upsample2_nhwc: bad dtype %d", dtype);
+    SG_REQUIRE(sg_dtype_ok(dtype), "srcgan_upsample2_nhwc: bad dtype %d", dtype);
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(C % epp == 0 && s_cs % epp == 0 && s_coff % epp == 0 && d_cs % epp == 0 && C <= d_cs, "srcgan_upsample2_nhwc: channel counts/strides must be multiples of %d", epp);
     const long nvec = (long)B * 4 * H * W * (C / epp);
-    if (dtype == SRCGAN_F32)
-        hipLaunchKernelGGL(upsample2_nhwc_k<float>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)src, s_cs, s_coff, s_plane, (float*)dst, d_cs, H, W, C, nvec);
-    else
-        hipLaunchKernelGGL(upsample2_nhwc_k<__bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, s_cs, s_coff, s_plane, (__bf16*)dst, d_cs, H, W, C, nvec);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(upsample2_nhwc_k<T>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const T*)src, s_cs, s_coff, s_plane, (T*)dst, d_cs, H, W, C, nvec));
     SG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int srcgan_sum2x2_nhwc(const void* src, int s_cs, void* dst, int d_cs, const void* mz, int m_cs, float mslope,
                                   int B, int H, int W, int C, int dtype, void* stream) {
     SG_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "srcgan_sum2x2_nhwc: bad arguments");
-    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "srcgan_sum2x2_nhwc: bad dtype %d", dtype);
+    SG_REQUIRE(sg_dtype_ok(dtype), "srcgan_sum2x2_nhwc: bad dtype %d", dtype);
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(C % epp == 0 && s_cs % epp == 0 && d_cs % epp == 0 && (!mz || m_cs % epp == 0), "srcgan_sum2x2_nhwc: channel counts/strides must be multiples of %d", epp);
     const long nvec = (long)B * H * W * (C / epp);
-    if (dtype == SRCGAN_F32)
-        hipLaunchKernelGGL(sum2x2_nhwc_k<float>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)src, s_cs, (float*)dst, d_cs, (const float*)mz, m_cs, mslope, H, W, C, nvec);
-    else
-        hipLaunchKernelGGL(sum2x2_nhwc_k<__bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, s_cs, (__bf16*)dst, d_cs, (const __bf16*)mz, m_cs, mslope, H, W, C, nvec);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sum2x2_nhwc_k<T>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const T*)src, s_cs, (T*)dst, d_cs, (const T*)mz, m_cs, mslope, H, W, C, nvec));
     SG_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,7 @@
 #define DISPATCH_DTYPE(dtype, ...) \
     if ((dtype) == SRCGAN_F32) { using T = float; __VA_ARGS__; } \
     else if ((dtype) == SRCGAN_BF16) { using T = __bf16; __VA_ARGS__; } \
+    else if ((dtype) == SRCGAN_F16) { using T = _Float16; __VA_ARGS__; } \
     else SG_FAIL("bad dtype %d", (int)(dtype));
 
 namespace {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void gn_param_grad_k(const float* __restrict__
 
 static int gn_check(const char* who, int B, long hw, int C, int G, int dtype) {
     SG_REQUIRE(B > 0 && hw > 0 && C > 0 && G > 0 && C % G == 0 && C <= 1024, "%s: bad B/HW/C/G (C <= 1024, G | C)", who);
-    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "%s: bad dtype %d", who, dtype);
+    SG_REQUIRE(sg_dtype_ok(dtype), "%s: bad dtype %d", who, dtype);
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(C % epp == 0 && 256 % (C / epp) == 0, "%s: C/%d must divide 256", who, epp);
     return 0;

@@ -161,7 +161,7 @@ static int log2i(int v) { int n = 0; while ((1 << n) < v) ++n; return n; }
 
 static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     SG_REQUIRE(c, "rddbnet: null cfg");
-    SG_REQUIRE(c->dtype == SRCGAN_F32 || c->dtype == SRCGAN_BF16, "rddbnet: bad dtype %d", c->dtype);
+    SG_REQUIRE(sg_dtype_ok(c->dtype), "rddbnet: bad dtype %d", c->dtype);
     SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8 && c->out_ch > 0 && c->out_ch <= 8, "rddbnet: in/out channels must be in 1..8");
     SG_REQUIRE(c->nf > 0 && c->gc > 0 && c->nf % 8 == 0 && c->gc % 8 == 0, "rddbnet: nf and gc must be multiples of 8 (nf=%d gc=%d)", c->nf, c->gc);
     SG_REQUIRE(c->nb >= 1 && c->B > 0 && c->H > 0 && c->W > 0, "rddbnet: bad nb/B/H/W");
@@ -193,7 +193,7 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
     P.kce = 64 / P.esz; P.nplane = (P.C + P.kce - 1) / P.kce; P.plane_bytes = (long)B * P.Ht * P.Wt * 64;
     // one bit per element for LeakyReLU' (instead of re-reading the activation in the backward pass): bf16, 32-channel slices
     static const bool no_sign = sg_env("SRCGAN_NO_SIGNMASK") != nullptr || sg_env("SRCGAN_DMA_CFG") != nullptr;
-    P.bm_bytes = (!no_sign && c->dtype == SRCGAN_BF16 && c->gc == 32 && c->nf % 32 == 0 && c->legacy != 2) ? (long)B * P.Ht * P.Wt * 4 : 0;
+    P.bm_bytes = (!no_sign && sg_is16(c->dtype) && c->gc == 32 && c->nf % 32 == 0 && c->legacy != 2) ? (long)B * P.Ht * P.Wt * 4 : 0;
     P.bm = align_up((size_t)P.nplane * P.plane_bytes, 256);
     P.szA = align_up(P.bm + 4 * (size_t)P.bm_bytes, 256);
     P.A = b.take(P.szA * (c->legacy == 2 ? 1 : 3 * P.nrr));        // legacy RDDBNet discards its trunk: one buffer holds conv_first's output
@@ -704,7 +704,7 @@ struct DPlan {
 
 static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     SG_REQUIRE(c, "nlayerd: null cfg");
-    SG_REQUIRE(c->dtype == SRCGAN_F32 || c->dtype == SRCGAN_BF16, "nlayerd: bad dtype");
+    SG_REQUIRE(sg_dtype_ok(c->dtype), "nlayerd: bad dtype");
     SG_REQUIRE(c->in_ch > 0 && c->in_ch <= 8, "nlayerd: input_nc must be in 1..8");
     SG_REQUIRE(c->ndf > 0 && c->ndf % 8 == 0, "nlayerd: ndf must be a multiple of 8");
     SG_REQUIRE(c->n_layers >= 1 && c->n_layers <= 5, "nlayerd: n_layers must be in 1..5");
@@ -1105,7 +1105,7 @@ struct RdBuilder {
 };
 
 static int rd_common(int dtype, int B, int H, int W, RdPlan& P, const char* who) {
-    SG_REQUIRE(dtype == SRCGAN_F32 || dtype == SRCGAN_BF16, "%s: bad dtype %d", who, dtype);
+    SG_REQUIRE(sg_dtype_ok(dtype), "%s: bad dtype %d", who, dtype);
     SG_REQUIRE(B > 0 && H > 0 && W > 0, "%s: bad B/H/W", who);
     P.dtype = dtype; P.esz = dtype == SRCGAN_F32 ? 4 : 2; P.B = B;
     return 0;

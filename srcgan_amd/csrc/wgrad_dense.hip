@@ -131,9 +131,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
         } else {
             const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
             const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
-            bf16x8 ones;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+            const bf16x8 ones = sg_ones16<T>();
 #pragma unroll 2
             for (int kk = 0; kk < TH * 2; ++kk) {
                 const int py = kk >> 1, xh = (kk & 1) * 16;
@@ -144,9 +142,9 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_k(const WdP p) {
                 for (int tap = 0; tap < NTAP; ++tap) {
                     const int ky = tap / 3, kx = tap % 3;
                     const char* bb = my_x + ((py + ky) * IWT + px0 + kx) * PB + choff;
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_frag2(bb, bb + 4 * PB), acc[tap], 0, 0, 0);
+                    acc[tap] = sg_mfma16<T>(a, tr_frag2(bb, bb + 4 * PB), acc[tap]);
                 }
-                if (do_bias) acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[NTAP], 0, 0, 0);
+                if (do_bias) acc[NTAP] = sg_mfma16<T>(a, ones, acc[NTAP]);
             }
         }
     }
@@ -205,9 +203,8 @@ __device__ __forceinline__ void wd_dma16(const void* base, int voff, int soff, w
 #ifndef SG_WD_EXP
 #define SG_WD_EXP 0
 #endif
-template <int MT, int NT, int TH>
+template <typename T, int MT, int NT, int TH>
 __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) {
-    using T = __bf16;
     using D = DT<T>;
     constexpr int NW = MT * NT, TW = 32, NTAP = 9;
     constexpr int IHT = TH + 2, IWT = TW + 2;
@@ -316,9 +313,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
     }
     const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
     const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    const bf16x8 ones = sg_ones16<T>();
     int stage = 0;
     for (int t = t_begin; t < t_end; ++t, stage ^= 1) {
 #ifdef SG_TRACE
@@ -398,7 +393,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
             for (int py = 0; py < TH; ++py) {
                 const int ky = i2 - py;
                 if (ky < 0 || ky > 2) continue;
-                if (!(SG_WD_EXP & 2)) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx], 0, 0, 0);
+                if (!(SG_WD_EXP & 2)) acc[ky * 3 + kx] = sg_mfma16<T>(fa[py][xh], fb[G % (PD + 1)], acc[ky * 3 + kx]);
                 else asm volatile("" :: "v"(fa[py][xh]), "v"(fb[G % (PD + 1)]));
             }
             // bias pseudo-tap: one MFMA per gradient fragment, placed in the light groups of the first/last input rows
@@ -406,7 +401,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
             if (do_bias && kx == 0 && (i2 == 0 || i2 >= IHT - 2))
 #pragma unroll
                 for (int py = (i2 == 0 ? 0 : i2 == IHT - 2 ? 1 : TH / 2); py < (i2 == 0 ? 1 : i2 == IHT - 2 ? TH / 2 : TH); ++py)
-                    acc[NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[py][xh], ones, acc[NTAP], 0, 0, 0);
+                    acc[NTAP] = sg_mfma16<T>(fa[py][xh], ones, acc[NTAP]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -485,7 +480,7 @@ static int launch_wd(WdP p, hipStream_t st) {
         fast = !no_fast && p.H % TH == 0 && p.W % 32 == 0 && span_dy < 2.0e9 && span_x < 2.0e9 &&
                (p.dyplane == 64 || (p.dycoff + p.g_base) % 32 == 0) && (p.xplane == 64 || p.xcoff % 32 == 0);
         constexpr int IPWF = (MT * (TH * 2) + NT * (((TH + 2) * 34 + 15) / 16) + MT * NT - 1) / (MT * NT);      // pieces per wave
-        if constexpr (IPWF <= 10) { if (fast) kern = wgrad_dense_fast_k<MT, NT, TH>; }   // larger tables would spill beside 160 accumulators
+        if constexpr (IPWF <= 10) { if (fast) kern = wgrad_dense_fast_k<T, MT, NT, TH>; }   // larger tables would spill beside 160 accumulators
         else fast = false;
     }
     static bool attr_set[2] = {false, false};
@@ -498,7 +493,7 @@ static int launch_wd(WdP p, hipStream_t st) {
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
     char cls[96];
-    snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d%s>", sizeof(T) == 4 ? "f32" : "bf16", MT, NT, fast ? ",fast" : "");
+    snprintf(cls, sizeof(cls), "wgrad_dense<%s,MT%d,NT%d%s>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, NT, fast ? ",fast" : "");
     const double px = (double)p.B * p.H * p.W;
     const int rows = (p.G - p.g_base) < 32 * MT ? (p.G - p.g_base) : 32 * MT;
     // algorithmic work = the (gradient channel, input channel) pairs some convolution of the block owns (the triangle), not
@@ -573,7 +568,7 @@ static int dispatch_wd(const WdP& p, int mt, int nt, hipStream_t st, int& nsplit
 // Input-channel tiles per workgroup: a row group of <= 64 gradient channels takes 4 (128 input channels, 8 waves)
 // instead of 2 -- the 2x2-wave form left one wave per SIMD (640 TFLOP/s against 1000 for the 4x2 form) and staged
 // the gradient planes once per 64 input channels.
-static int wd_nt(int mt, int cin_max, int dtype) { return (dtype == SRCGAN_BF16 && mt <= 2 && cin_max > 64) ? 4 : 2; }
+static int wd_nt(int mt, int cin_max, int dtype) { return (sg_is16(dtype) && mt <= 2 && cin_max > 64) ? 4 : 2; }
 
 // pixel splits per row group: fill the chip once (workgroups resident per CU follow from the LDS tile)
 static int wd_nsplit(int mt, int nt, int ncit, int dtype, int B, int H, int W) {
@@ -592,7 +587,7 @@ extern "C" size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, 
     size_t mx = 0;
     for (int g_base = 0; g_base < G; g_base += 128) {
         const int rows = G - g_base < 128 ? G - g_base : 128, mt = cdiv(rows, 32);
-        for (int nt = 2; nt <= (dtype == SRCGAN_BF16 && mt <= 2 ? 4 : 2); nt += 2) {                 // either column-tile form may be chosen at run time
+        for (int nt = 2; nt <= (sg_is16(dtype) && mt <= 2 ? 4 : 2); nt += 2) {                 // either column-tile form may be chosen at run time
             const int ncit = cdiv(C, 32 * nt);
             const size_t b = (size_t)wd_nsplit(mt, nt, ncit, dtype, B, H, W) * ncit * 10 * (32 * mt) * (32 * nt) * sizeof(float);
             if (b > mx) mx = b;
@@ -603,7 +598,7 @@ extern "C" size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, 
 
 extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream) {
     SG_REQUIRE(d && d->dy && d->x && d->slab, "srcgan_wgrad_dense: null pointer");
-    SG_REQUIRE(d->dtype == SRCGAN_F32 || d->dtype == SRCGAN_BF16, "srcgan_wgrad_dense: bad dtype %d", d->dtype);
+    SG_REQUIRE(sg_dtype_ok(d->dtype), "srcgan_wgrad_dense: bad dtype %d", d->dtype);
     const int esz = d->dtype == SRCGAN_F32 ? 4 : 2, epp = 16 / esz;
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->G > 0 && d->C > 0 && d->nseg > 0 && d->nseg <= 8,
                "srcgan_wgrad_dense: bad dimensions");
@@ -645,6 +640,7 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
         p.nsplit = wd_nsplit(mt, nt, p.ncit, d->dtype, d->B, d->H, d->W);
         int ns = 0;
         if (d->dtype == SRCGAN_F32) SG_TRY(dispatch_wd<float>(p, mt, nt, st, ns));
+        else if (d->dtype == SRCGAN_F16) SG_TRY(dispatch_wd<_Float16>(p, mt, nt, st, ns));
         else SG_TRY(dispatch_wd<__bf16>(p, mt, nt, st, ns));
         WdRedP q;
         memset(&q, 0, sizeof(q));

@@ -10,7 +10,7 @@ import torch
 
 from . import _native as N
 
-TORCH_DT = {N.F32: torch.float32, N.BF16: torch.bfloat16}
+TORCH_DT = {N.F32: torch.float32, N.BF16: torch.bfloat16, N.F16: torch.float16}
 
 
 def to_nhwc(x: torch.Tensor, cs: Optional[int] = None, dtype=None) -> torch.Tensor:

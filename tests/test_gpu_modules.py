@@ -485,6 +485,83 @@ def test_stacked_generators_x8_vs_oracle():
             assert rel_err(p.grad.cpu(), ref[k].grad) < F32_TOL, k
 
 
+def test_fp16_generator_and_discriminator_vs_oracle():
+    """SRCGAN_F16 (BASELINE configs[4] asks for fp16 + MFMA): the same kernels on IEEE half.  Full-width generator (nb=2, x4) and
+    3-layer PatchGAN against the f32 oracle AND the oracle with fp16 storage (oracle.storage(torch.float16)).  The loss is scaled
+    by 4096 before backward and the gradients divided by it (half's smallest normal is 6e-5; an unscaled L1 gradient 1/N is
+    subnormal): what srcgan_amd.train.StackedSR(loss_scale=...) does.  11 significant bits: ~8x closer than bf16."""
+    from srcgan_amd import RDDBNet, NLayerDiscriminator, MSELoss, GANLoss
+    S = 4096.0
+    sd = oracle.rddbnet_state(3, 3, 4, 64, 2, 32, seed=3)
+    net = _load(RDDBNet(3, 3, 4, nf=64, nb=2, gc=32, dtype="fp16"), sd)
+    torch.manual_seed(0)
+    x, t = torch.rand(2, 3, 19, 35), torch.rand(2, 3, 76, 140)
+
+    def ref(store):
+        r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        if store:
+            with oracle.storage(torch.float16):
+                yr = oracle.rddbnet_forward(r, xr, 4)
+        else:
+            yr = oracle.rddbnet_forward(r, xr, 4)
+        oracle.mse_loss(yr, t).backward()
+        return yr.detach(), xr.grad, r
+    (yr, dxr, rr), (ye, dxe, re_) = ref(False), ref(True)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    (MSELoss()(y, t.cuda()) * S).backward()
+    assert rel_l2(y.cpu(), yr) < 2e-3 and rel_l2(y.cpu(), ye) < 2e-3
+    assert rel_l2(xg.grad.cpu() / S, dxr) < 2e-2
+    worst = max((rel_l2(p.grad.cpu() / S, rr[k].grad), k) for k, p in net.named_parameters())
+    assert worst[0] < 1e-2, worst
+    # discriminator
+    dsd = oracle.nlayer_d_state(3, 64, 3, seed=5)
+    dnet = _load(NLayerDiscriminator(3, 64, 3, dtype="fp16"), dsd)
+    xd = torch.rand(2, 3, 96, 128)
+    def dref(store):
+        rd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in dsd.items()}
+        if store:
+            with oracle.storage(torch.float16):
+                yo = oracle.nlayer_d_forward(rd, xd, True)
+        else:
+            yo = oracle.nlayer_d_forward(rd, xd, True)
+        oracle.gan_loss(yo, False).backward()
+        return rd
+    rd, rde = dref(False), dref(True)
+    yd = dnet(xd.cuda())
+    (GANLoss("lsgan", device="cuda")(yd, False) * S).backward()
+    rows = [(k, rel_l2(p.grad.cpu() / S, rd[k].grad), rel_l2(rde[k].grad, rd[k].grad), rel_l2(p.grad.cpu() / S, rde[k].grad)) for k, p in dnet.named_parameters()]
+    print("fp16 discriminator (name, native vs f32, fp16-storage oracle vs f32, native vs fp16-storage oracle):", sorted(rows, key=lambda r: -r[1])[:4])
+    for k, e_f32, fmt, e_emu in rows:          # yardstick as in test_nlayerd_full_width_vs_oracle (bf16: ~10 % vs f32 here)
+        assert e_f32 < 1.5 * fmt + 5e-3 and e_f32 < 8e-2, (k, e_f32, fmt, e_emu)
+
+
+def test_stacked_sr_micro_batches_equal_the_full_batch():
+    """StackedSR (BASELINE configs[4] harness): gradient accumulation over micro-batches is the full-batch step -- the generator has
+    no cross-sample coupling -- and a loss scale leaves the step unchanged (fp32: to rounding)."""
+    from srcgan_amd.train import StackedSR
+    g = torch.Generator().manual_seed(21)
+    x, y = torch.rand(4, 3, 16, 12, generator=g).cuda(), torch.rand(4, 3, 128, 96, generator=g).cuda()
+    outs = []
+    for mb, scale in ((None, 1.0), (1, 1.0), (2, 256.0)):
+        torch.manual_seed(5)
+        m = StackedSR(ups=(4, 2), nf=16, nb=1, gc=8, dtype="fp32", device="cuda", micro_batch=mb, loss_scale=scale)
+        for _ in range(2):
+            m.optimize_parameters(x, y)
+        outs.append(([p.detach().clone() for p in m.parameters()], float(m.loss)))
+    for ps, loss in outs[1:]:
+        assert abs(loss - outs[0][1]) < 1e-5 * abs(outs[0][1])
+        assert max(rel_err(a, b) for a, b in zip(ps, outs[0][0])) < 1e-4
+    # fp16 with a loss scale: finite, and close to the fp32 step
+    torch.manual_seed(5)
+    m = StackedSR(ups=(4, 2), nf=16, nb=1, gc=8, dtype="fp16", device="cuda", micro_batch=2, loss_scale=1024.0)
+    for _ in range(2):
+        m.optimize_parameters(x, y)
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    assert abs(float(m.loss) - outs[0][1]) < 2e-2 * abs(outs[0][1])
+
+
 def test_empty_batch_generator():
     """An empty batch gives an empty output of the right shape and zero parameter gradients (aten::convolution's behaviour on
     the reference side), not a kernel launch."""
