@@ -96,7 +96,9 @@ class StackedSR:
     what it buys is memory: the dense-block activations of a 512x512 trunk are 7.2 GB per image in 16-bit storage, 231 GB for the
     configuration's 32 images per GPU; 16-image slices need half of that.
     ``loss_scale``: multiplies the loss before backward and divides the gradients before the step (fp16 storage: gradients below
-    2^-24 would vanish; bf16 and fp32 need none)."""
+    2^-24 would vanish; bf16 and fp32 need none).  With a scale the gradients are checked in the same multi-tensor pass that
+    unscales them: a step with a non-finite gradient is skipped and the scale halved (``skipped_steps`` counts them), as
+    torch.cuda.amp.GradScaler does -- half precision overflows at 65504."""
 
     def __init__(self, ups=(4, 2), in_ch=3, out_ch=3, nf=64, nb=23, gc=32, dtype=None, device="cuda", lr=1e-4,
                  micro_batch: Optional[int] = None, loss_scale: float = 1.0):
@@ -107,6 +109,7 @@ class StackedSR:
         self.optimizer = Adam(itertools.chain(*[n.parameters() for n in self.nets]), lr=lr)
         self.micro_batch = micro_batch
         self.loss_scale = float(loss_scale)
+        self.skipped_steps = 0
         self.grad_sync = None
 
     def parameters(self):
@@ -131,10 +134,17 @@ class StackedSR:
             del out, loss
         if self.grad_sync is not None and not self.grad_sync.attached:
             self.grad_sync.allreduce(self.parameters())
-        if self.loss_scale != 1.0:
-            torch._foreach_mul_([p.grad for p in self.parameters() if p.grad is not None], 1.0 / self.loss_scale)
-        self.optimizer.step()
         self.loss = total
+        if self.loss_scale != 1.0:
+            grads = [p.grad for p in self.parameters() if p.grad is not None]
+            found_inf = torch.zeros(1, device=grads[0].device)
+            inv = torch.full((1,), 1.0 / self.loss_scale, device=grads[0].device)
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv)
+            if float(found_inf) != 0.0:          # (one host sync per step, scaled mode only)
+                self.skipped_steps += 1
+                self.loss_scale = max(1.0, self.loss_scale * 0.5)
+                return
+        self.optimizer.step()
 
 
 class ImagePool:
