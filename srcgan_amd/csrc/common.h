@@ -63,6 +63,13 @@ template <typename T> __device__ __forceinline__ f32x16 sg_mfma16(bf16x8 a, bf16
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16x16x32 form (f32x4 result: column = lane & 15, row = 4 * (lane >> 4) + register; operands: row / column lane & 15, k = 8 * (lane >> 4) + j)
+template <typename T> __device__ __forceinline__ f32x4 sg_mfma16s(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16))
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // eight copies of 1.0 in T, as a fragment (bias gradients: a pseudo-tap whose B operand is all ones)
 template <typename T> __device__ __forceinline__ bf16x8 sg_ones16() {
     typedef __attribute__((ext_vector_type(8))) T v8;

@@ -252,36 +252,49 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
 #endif
 
     // ---- per-wave piece table: per-lane offset from the tile origin, channel-plane offset (uniform), border class
-    int voff[IPW], soff[IPW];
+    int voff[IPW]; long soff[IPW];          // soff: channel-plane offset, 64-bit and wave-uniform (a blocked 1024x1024 batch spans > 2^31 bytes)
     unsigned cls[2] = {0u, 0u};
     {
         const int part = lane & 3, lpx = lane >> 2;
 #pragma unroll
         for (int it = 0; it < IPW; ++it) {
             const int pi = it * NW + wave;
-            int v = OOB, so = 0;
+            int v = OOB; long so = 0;
             if (pi < MT * DPP) {
                 const int m = pi / DPP, pix = (pi - m * DPP) * PXP + lpx;
                 const int ch = p.g_base + m * 32 + part * D::EPP;
                 if (pix < DPX && ch < p.G) v = ((pix / TW) * p.W + pix % TW) * (int)p.dypix + part * 16;
-                so = (int)wd_chan_off<T>(p.dycoff + p.g_base + m * 32, p.dyplane);
+                so = (long)wd_chan_off<T>(p.dycoff + p.g_base + m * 32, p.dyplane);
             } else if (pi < NPIECE) {
                 const int pj = pi - MT * DPP, n = pj / XPP, pix = (pj - n * XPP) * PXP + lpx;
                 const int iy = pix / IWT, ix = pix - iy * IWT;
                 const int ch = (cit * NT + n) * 32 + part * D::EPP;
                 if (pix < XPX && ch < p.C) v = (iy * p.W + ix) * (int)p.xpix + part * 16;
-                so = (int)wd_chan_off<T>(p.xcoff + (cit * NT + n) * 32, p.xplane);
+                so = (long)wd_chan_off<T>(p.xcoff + (cit * NT + n) * 32, p.xplane);
                 cls[it / 8] |= (unsigned)((iy == 0) | ((iy == IHT - 1) << 1) | ((ix == 0) << 2) | ((ix == IWT - 1) << 3)) << (4 * (it % 8));
             }
-            voff[it] = v; soff[it] = __builtin_amdgcn_readfirstlane(so);
+            voff[it] = v;
+            soff[it] = ((long)__builtin_amdgcn_readfirstlane((int)(so >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(so & 0xffffffff));
         }
     }
 
-    f32x16 acc[NTAP + 1];
+    // MFMA shape.  S16 = 1: four 16x16x32 MFMAs per (tap, 32 pixels) instead of two 32x32x16 -- same cycles per FLOP, same LDS
+    // bytes, same 160 accumulator registers; the kernel runs power-limited (1.9-2.0 GHz in the training step) and the chip
+    // holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+#ifndef SG_WD_S16
+#define SG_WD_S16 1
+#endif
+    constexpr bool S16 = SG_WD_S16 != 0;
+    f32x16 acc[S16 ? 1 : NTAP + 1];
+    f32x4 acq[S16 ? NTAP + 1 : 1][2][2];          // [tap][16-row block of g][16-column block of ci]
 #pragma unroll
-    for (int a = 0; a <= NTAP; ++a)
+    for (int a = 0; a < (S16 ? 1 : NTAP + 1); ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < (S16 ? NTAP + 1 : 1); ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acq[a][(i >> 3) & 1][(i >> 2) & 1][i & 3] = 0.f;
 
     const int t_begin = (int)((long)p.ntiles * split / p.nsplit);
     const int t_end = (int)((long)p.ntiles * (split + 1) / p.nsplit);
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
         if (IPW * NW != NPIECE && pi >= NPIECE) return;
         int v = ((clm[it / 8] >> (4 * (it % 8))) & 15u) ? OOB : voff[it];
         if (SG_WD_EXP & 8) v = OOB;
-        wd_dma16(pi < MT * DPP ? dyo : xo, v, soff[it], (wd_lptr_t)(smem + stage * SBYTES + pi * 1024));
+        wd_dma16((pi < MT * DPP ? dyo : xo) + soff[it], v, 0, (wd_lptr_t)(smem + stage * SBYTES + pi * 1024));
     };
 
     if (t_begin < t_end) {
@@ -348,6 +361,55 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
 #ifndef SG_WD_PD
 #define SG_WD_PD 4
 #endif
+        if constexpr (S16) {
+            // Groups G = (input row i2, tap column kx); a group's fragments cover all 32 pixels of the row (k = 8 * (lane >> 4) + j)
+            // for the two 16-channel halves: gradient fragments fa[py][cb] are read once per tile, input fragments fb[..][cb] once
+            // per group and feed every (output row py, ky) with py + ky == i2.
+            constexpr int NG = IHT * 3, PDG = 1;
+            bf16x8 fa[TH][2], fb[PDG + 1][2];
+            const int kq = lane >> 4;                              // k-group: pixels 8 kq .. 8 kq + 7
+            const int cho = (4 * pp) * 2;
+            auto rd_b = [&](int G) {
+                const int i2 = G / 3, kx = G % 3;
+                const char* bb = my_x + (i2 * IWT + 8 * kq + qq + kx) * PB + cho;
+                fb[G % (PDG + 1)][0] = tr_frag2(bb, bb + 4 * PB);
+                fb[G % (PDG + 1)][1] = tr_frag2(bb + 32, bb + 32 + 4 * PB);
+            };
+            auto rd_a = [&](int py) {
+                const char* ab = my_d + (py * TW + 8 * kq + qq) * PB + cho;
+                fa[py][0] = tr_frag2(ab, ab + 4 * PB);
+                fa[py][1] = tr_frag2(ab + 32, ab + 32 + 4 * PB);
+            };
+            rd_a(0); rd_b(0);
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                const int i2 = G / 3, kx = G % 3;
+                if (kx == 1 && i2 + 1 < TH) rd_a(i2 + 1);          // row py is first used by group 3 * py
+                if (G + PDG < NG) rd_b(G + PDG);
+                if (more) {              // next tile's pieces ride in the shadow of this tile's MFMAs
+#pragma unroll
+                    for (int j = 0; j < 2 * PPK; ++j)
+                        if (2 * PPK * G + j < IPW) piece(2 * PPK * G + j, stage ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int py = 0; py < TH; ++py) {
+                    const int ky = i2 - py;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acq[ky * 3 + kx][mb][nb] = sg_mfma16s<T>(fa[py][mb], fb[G % (PDG + 1)][nb], acq[ky * 3 + kx][mb][nb]);
+                }
+                if (do_bias && kx == 0 && (i2 == 0 || i2 >= IHT - 2))
+#pragma unroll
+                    for (int py = (i2 == 0 ? 0 : i2 == IHT - 2 ? 1 : TH / 2); py < (i2 == 0 ? 1 : i2 == IHT - 2 ? TH / 2 : TH); ++py)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acq[NTAP][mb][0] = sg_mfma16s<T>(fa[py][mb], ones, acq[NTAP][mb][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         constexpr int NGRP = IHT * 3 * 2, PD = SG_WD_PD;
         bf16x8 fa[TH][2], fb[PD + 1];
         auto read_b = [&](int G) {
@@ -404,6 +466,7 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
                     acc[NTAP] = sg_mfma16<T>(fa[py][xh], ones, acc[NTAP]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
     }
 
     constexpr int COT = 32 * MT, CIT = 32 * NT;
@@ -411,10 +474,23 @@ __global__ __launch_bounds__(MT * NT * 64) void wgrad_dense_fast_k(const WdP p) 
 #pragma unroll
     for (int tap = 0; tap <= NTAP; ++tap) {
         if (tap == NTAP && !do_bias) continue;
+        if constexpr (S16) {
+            // 16x16 result block: column = lane & 15, row = 4 * (lane >> 4) + register
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = wm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-            sp[((size_t)tap * COT + row) * CIT + wn * 32 + r] = acc[tap][i];
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = wm * 32 + mb * 16 + 4 * (lane >> 4) + i;
+                        sp[((size_t)tap * COT + row) * CIT + wn * 32 + nb * 16 + (lane & 15)] = acq[tap][mb][tap == NTAP ? 0 : nb][i];
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = wm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                sp[((size_t)tap * COT + row) * CIT + wn * 32 + r] = acc[tap][i];
+            }
         }
     }
 }
@@ -475,8 +551,9 @@ static int launch_wd(WdP p, hipStream_t st) {
     if constexpr (!std::is_same<T, float>::value) {
         // whole tiles, 32-channel-aligned slices when planar, and every byte offset within 31 bits
         static const bool no_fast = sg_env("SRCGAN_WD_SLOW") != nullptr;
-        const double span_dy = p.dyplane != 64 ? (double)p.dyplane * cdiv(p.dycoff + p.G, 32) : (double)p.B * p.H * p.W * p.dypix;
-        const double span_x = p.xplane != 64 ? (double)p.xplane * cdiv(p.xcoff + p.C, 32) : (double)p.B * p.H * p.W * p.xpix;
+        // per-lane offsets are relative to a tile's origin (64-bit, uniform) and the channel-plane offset is 64-bit too: only a
+        // tile's own extent must fit 31 bits
+        const double span_dy = (double)(TH + 2) * p.W * p.dypix, span_x = (double)(TH + 4) * p.W * p.xpix;
         fast = !no_fast && p.H % TH == 0 && p.W % 32 == 0 && span_dy < 2.0e9 && span_x < 2.0e9 &&
                (p.dyplane == 64 || (p.dycoff + p.g_base) % 32 == 0) && (p.xplane == 64 || p.xcoff % 32 == 0);
         constexpr int IPWF = (MT * (TH * 2) + NT * (((TH + 2) * 34 + 15) / 16) + MT * NT - 1) / (MT * NT);      // pieces per wave
