@@ -315,7 +315,7 @@ int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const float* dy_nchw
 
 /* ResDeconv colouriser (resdeconv.py:99-195; C network of trainCas.py:31,99-100): [B,3,H,W] f32 NCHW -> [B,tar_ch,H,W];
  * H, W multiples of 16.  params/grads in state_dict order (conv1.weight, bn1.{weight,bias}, layer1.0.conv1.weight, ...,
- * pred.weight); a null grads[i] skips that gradient.  No gradient w.r.t. the input (it is data in every harness). */
+ * pred.weight); a null grads[i] skips that gradient.  The input gradient is optional (the reference harnesses feed data). */
 typedef struct srcgan_resdeconv_cfg {
     int in_ch, out_ch;     /* in_ch must be 3 (a 1-channel source is replicated by the caller, resdeconv.py:166-167) */
     int B, H, W;
@@ -326,12 +326,13 @@ size_t srcgan_resdeconv_ws_bytes(const srcgan_resdeconv_cfg* c);
 size_t srcgan_resdeconv_bwd_scratch_bytes(const srcgan_resdeconv_cfg* c);
 int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const float* x_nchw, const float* const* params, void* ws,
                              float* y_nchw, void* stream);
+/* dx_nchw: gradient w.r.t. the input [B,3,H,W] f32, or NULL */
 int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws,
-                              void* scratch, float* const* grads, void* stream);
+                              void* scratch, float* const* grads, float* dx_nchw, void* stream);
 
 /* SR networks selectable as --SRModel (trainCas.py:169): kind 0 = ESPCN (espcn.py:18-51; the CLI default), kind 1 = SRCNN
  * (srcnn.py:17-42), kind 2 = EDSR (edsr.py:37-110: GroupNorm residual blocks, [B,out_ch,H*up,W*up]).  [B,in_ch,H,W] f32 NCHW -> ESPCN [B,out_ch,H*up,W*up] / SRCNN [B,out_ch,H,W].  params/grads in state_dict
- * order (conv1.weight, conv1.bias, ...).  No gradient w.r.t. the input. */
+ * order (conv1.weight, conv1.bias, ...).  dx_nchw: gradient w.r.t. the input [B,in_ch,H,W] f32, or NULL. */
 typedef struct srcgan_srnet_cfg {
     int kind, in_ch, out_ch, up, base;     /* base = base_kernel / base_channel (64) */
     int B, H, W;
@@ -343,7 +344,7 @@ size_t srcgan_srnet_ws_bytes(const srcgan_srnet_cfg* c);
 size_t srcgan_srnet_bwd_scratch_bytes(const srcgan_srnet_cfg* c);
 int srcgan_srnet_forward(const srcgan_srnet_cfg* c, const float* x_nchw, const float* const* params, void* ws, float* y_nchw, void* stream);
 int srcgan_srnet_backward(const srcgan_srnet_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
-                          float* const* grads, void* stream);
+                          float* const* grads, float* dx_nchw, void* stream);
 
 /* nn.PixelShuffle(r) on NHWC (espcn.py:44,50): src [B,H,W,C*r*r] -> dst [B,H*r,W*r,C]; inverse = 1: the adjoint, src [B,H*r,W*r,C]
  * -> dst [B,H,W,C*r*r].  srcgan_mask_inplace: g *= (act > 0 ? 1 : slope) over n elements (ReLU' / LeakyReLU' on an incoming gradient). */

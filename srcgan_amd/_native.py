@@ -146,12 +146,12 @@ SIGNATURES = {
     "srcgan_resdeconv_ws_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_bwd_scratch_bytes": (_S, [C.POINTER(ResDeconvCfg)]),
     "srcgan_resdeconv_forward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P]),
-    "srcgan_resdeconv_backward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P, _P]),
+    "srcgan_resdeconv_backward": (_I, [C.POINTER(ResDeconvCfg), _P, _P, _P, _P, _P, _P, _P]),
     "srcgan_srnet_num_params": (_I, [C.POINTER(SrNetCfg)]),
     "srcgan_srnet_ws_bytes": (_S, [C.POINTER(SrNetCfg)]),
     "srcgan_srnet_bwd_scratch_bytes": (_S, [C.POINTER(SrNetCfg)]),
     "srcgan_srnet_forward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P]),
-    "srcgan_srnet_backward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P, _P]),
+    "srcgan_srnet_backward": (_I, [C.POINTER(SrNetCfg), _P, _P, _P, _P, _P, _P, _P]),
     "srcgan_pixel_shuffle_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "srcgan_mask_inplace": (_I, [_P, _P, _F, _L, _I, _P]),
     "srcgan_metric_scratch_floats": (_I, [_I, _I, _I, _I]),

@@ -288,6 +288,8 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
     SG_CASE(2, 1, 1, 2, false)
     SG_CASE(4, 4, 2, 1, true)
     SG_CASE(4, 4, 1, 2, true)
+    SG_CASE(3, 4, 1, 2, true)        // parity classes of the 7x7 stride-2 stem's input gradient (resdeconv.py:113): 3 or 4 taps per axis
+    SG_CASE(4, 3, 1, 2, true)
     SG_CASE(3, 3, 2, 1, false)
     SG_CASE(7, 7, 2, 1, true)        // ResDeconv stem (resdeconv.py:113)
     SG_CASE(1, 1, 2, 2, false)       // ResDeconv down-sample shortcut (resdeconv.py:12-15,157-161)

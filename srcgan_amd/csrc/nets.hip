@@ -990,6 +990,17 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
 // convolution with a fused ReLU is the gradient w.r.t. its pre-activation: whoever writes it applies the mask (the consumer's
 // dgrad epilogue, or srcgan_mask_inplace for the gradient arriving from the loss).
 namespace {
+// Input gradient of a k x k stride-2 convolution with padding `pad`, by output parity a (0 / 1) along one axis:
+//   dx[2 j + a] = sum over the kernel rows ky == (a + pad) mod 2 of dy[j + (a + pad - ky) / 2] * w[ky]
+// -> a stride-1 sub-convolution with n taps; tap t (ascending dy row) uses ky = ky_max - 2 t and needs `lead` rows above row j.
+struct Par2 { int n, ky_max, lead; };
+static inline Par2 par2(int k, int pad, int a) {
+    int ky_max = k - 1;
+    if (((ky_max ^ (a + pad)) & 1) != 0) --ky_max;
+    Par2 r; r.ky_max = ky_max; r.n = ky_max >= 0 ? ky_max / 2 + 1 : 0; r.lead = (ky_max - a - pad) / 2;
+    return r;
+}
+
 struct RdT { int C, cs, H, W, act; size_t off; };       // act: produced by a convolution with a fused ReLU
 struct RdOp {
     int type;                 // 0 conv (+bias)(+ReLU), 1 GroupNorm(+res)(+ReLU), 2 ConvTranspose2d k2 s2, 3 PixelShuffle(r)
@@ -1070,10 +1081,10 @@ struct RdBuilder {
             const RdT ti = P.T[o.in], to = P.T[o.out];
             if (o.type == 0) {
                 o.wf[0] = pk(to.C, ti.C, o.k * o.k);
-                if (o.in != 0) {
+                {       // (the input tensor's own gradient is produced on request: dx_nchw of the backward entry points)
                     if (o.s == 1) o.wd[0] = pk(ti.C, to.C, o.k * o.k);
                     else if (o.k == 1) o.wd[0] = pk(ti.C, to.C, 1);
-                    else for (int q = 0; q < 4; ++q) o.wd[q] = pk(ti.C, to.C, ((q >> 1) ? 2 : 1) * ((q & 1) ? 2 : 1));
+                    else for (int q = 0; q < 4; ++q) o.wd[q] = pk(ti.C, to.C, par2(o.k, o.pad, q >> 1).n * par2(o.k, o.pad, q & 1).n);
                 }
             } else if (o.type == 2) {
                 for (int q = 0; q < 4; ++q) o.wf[q] = pk(to.C, ti.C, 1);
@@ -1086,7 +1097,7 @@ struct RdBuilder {
         P.g.resize(P.T.size());
         long maxpix = 1;
         for (size_t i = 0; i < P.T.size(); ++i) {
-            P.g[i] = i == 0 ? 0 : s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
+            P.g[i] = s.take((size_t)B * P.T[i].H * P.T[i].W * P.T[i].cs * P.esz);
             if ((long)B * P.T[i].H * P.T[i].W > maxpix) maxpix = (long)B * P.T[i].H * P.T[i].W;
         }
         size_t slab = 0;
@@ -1223,7 +1234,7 @@ static int rd_forward(const RdPlan& P, const float* x_nchw, const float* const* 
     return 0;
 }
 
-static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const* params, void* ws, void* scratch, float* const* grads,
+static int rd_backward(const RdPlan& P, const float* dy_nchw, float* dx_nchw, const float* const* params, void* ws, void* scratch, float* const* grads,
                        const char* tag, void* st) {
     SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "%s backward: null pointer", tag);
     SG_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)scratch % 256) == 0, "%s backward: buffers must be 256-byte aligned", tag);
@@ -1235,13 +1246,14 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         PackList packs(dt, wp);
         for (const RdOp& o : P.ops) {
             const RdT ti = P.T[o.in], to = P.T[o.out];
-            if (o.type == 0 && o.in != 0) {
+            if (o.type == 0 && (o.in != 0 || dx_nchw)) {
                 if (o.s == 1) { const WLayout L = lay_dgrad_s1(ti.C, o.k, o.k); packs.add(params[o.w], wp + o.wd[0], ti.C, to.C, o.k, o.k, L.sr, L.sk, L.sty, L.stx, L.off); }
                 else if (o.k == 1) packs.add(params[o.w], wp + o.wd[0], ti.C, to.C, 1, 1, 1, (long)ti.C, 0, 0, 0);
                 else
-                    for (int q = 0; q < 4; ++q) {       // 3x3 s2 p1 dgrad by output parity (a,b): 1 or 2 taps per axis
-                        const int a = q >> 1, bb = q & 1;
-                        packs.add(params[o.w], wp + o.wd[q], ti.C, to.C, a ? 2 : 1, bb ? 2 : 1, 9, (long)ti.C * 9, -6, -2, (a ? 2 : 1) * 3 + (bb ? 2 : 1));
+                    for (int q = 0; q < 4; ++q) {       // stride-2 dgrad by output parity (a,b): par2() taps per axis (3x3 p1: 1 or 2; 7x7 p3: 3 or 4)
+                        const Par2 py = par2(o.k, o.pad, q >> 1), px = par2(o.k, o.pad, q & 1);
+                        const long kk = (long)o.k * o.k;
+                        packs.add(params[o.w], wp + o.wd[q], ti.C, to.C, py.n, px.n, kk, (long)ti.C * kk, -2 * o.k, -2, (long)py.ky_max * o.k + px.ky_max);
                     }
             } else if (o.type == 2) {
                 packs.add(params[o.w], wp + o.wd[0], ti.C, to.C, 2, 2, (long)to.C * 4, 4, 2, 1, 0);
@@ -1264,7 +1276,7 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
         const RdT ti = P.T[o.in], to = P.T[o.out];
         SG_REQUIRE(written[o.out], "%s backward: internal error (gradient of tensor %d missing)", tag, o.out);
         TRef xin = rd_t(w8, ti), dy = gt(o.out);
-        const bool need_dx = o.in != 0;
+        const bool need_dx = o.in != 0 || dx_nchw;
         TRef dx = need_dx ? gt(o.in) : TNULL;
         bool acc = need_dx && written[o.in];
         if (o.type == 0) {
@@ -1283,6 +1295,7 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
             if (o.bias >= 0 && G(o.bias) && !fused_bias) SG_TRY(bias_grad(dt, dy, (long)B * to.H * to.W, to.C, 1.f, G(o.bias), colscr, st));
             if (need_dx) {
                 SG_REQUIRE(!(acc && ti.act), "%s backward: internal error (activated tensor with two consumers)", tag);
+                if (o.in == 0 && !acc) SG_HIP(hipMemsetAsync(dx.p, 0, (size_t)B * ti.H * ti.W * ti.cs * P.esz, (hipStream_t)st));    // padded image channels
                 if (o.s == 1) {
                     Conv cv(dt, o.k, o.k, 1);
                     cv.in(dy, B, to.H, to.W, to.C < 8 ? to.cs : to.C).w(wp + o.wd[0]).out(dx, ti.H, ti.W, ti.C).pad(o.k - 1 - o.pad, o.k - 1 - o.pad);
@@ -1299,8 +1312,9 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
                     for (int q = 0; q < 4; ++q) {
                         const int a = q >> 1, bb = q & 1;
                         const int mh = (ti.H - a + 1) / 2, mw = (ti.W - bb + 1) / 2;
-                        Conv cv(dt, a ? 2 : 1, bb ? 2 : 1, 1);
-                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(0, 0).scatter(2, a, bb, ti.H, ti.W);
+                        const Par2 py = par2(o.k, o.pad, a), px = par2(o.k, o.pad, bb);
+                        Conv cv(dt, py.n, px.n, 1);
+                        cv.in(dy, B, to.H, to.W, to.C).w(wp + o.wd[q]).out(dx, mh, mw, ti.C).pad(py.lead, px.lead).scatter(2, a, bb, ti.H, ti.W);
                         if (acc) cv.res1(dx, ti.C, 1.f);
                         SG_TRY(cv.run(st));
                     }
@@ -1330,6 +1344,10 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, const float* const
             written[o.in] = 1;
         }
     }
+    if (dx_nchw) {       // gradient w.r.t. the network input (an end-to-end cascade: trainCas.py:108 feeds one network's output to the next)
+        SG_REQUIRE(written[0], "%s backward: internal error (no input gradient was produced)", tag);
+        SG_TRY(srcgan_nhwc_to_nchw_f32(s8 + P.g[0], dx_nchw, B, P.in_ch, P.H, P.W, P.in_cs, 0, dt, st));
+    }
     return 0;
 }
 }  // namespace
@@ -1343,10 +1361,10 @@ extern "C" int srcgan_resdeconv_forward(const srcgan_resdeconv_cfg* c, const flo
     return rd_forward(P, x_nchw, params, ws, y_nchw, "resdeconv", st);
 }
 extern "C" int srcgan_resdeconv_backward(const srcgan_resdeconv_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
-                                         float* const* grads, void* st) {
+                                         float* const* grads, float* dx_nchw, void* st) {
     RdPlan P;
     SG_TRY(rd_plan(c, P));
-    return rd_backward(P, dy_nchw, params, ws, scratch, grads, "resdeconv", st);
+    return rd_backward(P, dy_nchw, dx_nchw, params, ws, scratch, grads, "resdeconv", st);
 }
 
 extern "C" int srcgan_srnet_num_params(const srcgan_srnet_cfg* c) { RdPlan P; if (sr_plan(c, P)) return -1; return P.nparams; }
@@ -1358,8 +1376,8 @@ extern "C" int srcgan_srnet_forward(const srcgan_srnet_cfg* c, const float* x_nc
     return rd_forward(P, x_nchw, params, ws, y_nchw, c->kind == 0 ? "espcn" : c->kind == 1 ? "srcnn" : "edsr", st);
 }
 extern "C" int srcgan_srnet_backward(const srcgan_srnet_cfg* c, const float* dy_nchw, const float* const* params, void* ws, void* scratch,
-                                     float* const* grads, void* st) {
+                                     float* const* grads, float* dx_nchw, void* st) {
     RdPlan P;
     SG_TRY(sr_plan(c, P));
-    return rd_backward(P, dy_nchw, params, ws, scratch, grads, c->kind == 0 ? "espcn" : c->kind == 1 ? "srcnn" : "edsr", st);
+    return rd_backward(P, dy_nchw, dx_nchw, params, ws, scratch, grads, c->kind == 0 ? "espcn" : c->kind == 1 ? "srcnn" : "edsr", st);
 }

@@ -378,18 +378,18 @@ class _ResDeconvFn(torch.autograd.Function):
         cfg = ctx.cfg
         if ctx.ws is None:
             raise RuntimeError("ResDeconv backward called twice (activations were released)")
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("ResDeconv: no gradient w.r.t. the input (detach it: the reference harness feeds it data, trainCas.py:99-100,108)")
+        need_dx = ctx.needs_input_grad[0]
         dy = dy.contiguous().float()
+        dx = torch.empty(cfg.B, 3, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
         arena = _GradArena(params, [ctx.needs_input_grad[3 + i] for i in range(len(params))])
         grads = arena.views
         scratch = N.workspace(lib.srcgan_resdeconv_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         N.check(lib.srcgan_resdeconv_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
-                                              N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_resdeconv_backward")
+                                              N.ptr_array(grads), dx.data_ptr() if need_dx else None, N.stream_ptr(dy.device)), "srcgan_resdeconv_backward")
         ctx.ws = None
         if _phase_hooks.get("resdeconv") is not None:
             _phase_hooks["resdeconv"].phase_done(arena, params, cfg, 0, 0, 0)
-        return (None, None, None, *grads)
+        return (dx, None, None, *grads)
 
 
 class _BasicBlockHolder(_HolderOnly):
@@ -497,18 +497,18 @@ class _SrNetFn(torch.autograd.Function):
         cfg = ctx.cfg
         if ctx.ws is None:
             raise RuntimeError("backward called twice (activations were released)")
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("ESPCN/SRCNN: no gradient w.r.t. the input (the reference harness feeds data, trainCas.py:89-91)")
+        need_dx = ctx.needs_input_grad[0]
         dy = dy.contiguous().float()
+        dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
         arena = _GradArena(params, [ctx.needs_input_grad[2 + i] for i in range(len(params))])
         grads = arena.views
         scratch = N.workspace(lib.srcgan_srnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         N.check(lib.srcgan_srnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
-                                          N.ptr_array(grads), N.stream_ptr(dy.device)), "srcgan_srnet_backward")
+                                          N.ptr_array(grads), dx.data_ptr() if need_dx else None, N.stream_ptr(dy.device)), "srcgan_srnet_backward")
         ctx.ws = None
         if _phase_hooks.get("srnet") is not None:
             _phase_hooks["srnet"].phase_done(arena, params, cfg, 0, 0, 0)
-        return (None, None, *grads)
+        return (dx, None, *grads)
 
 
 class ESPCN(nn.Module):

@@ -562,6 +562,34 @@ def test_stacked_sr_micro_batches_equal_the_full_batch():
     assert abs(float(m.loss) - outs[0][1]) < 2e-2 * abs(outs[0][1])
 
 
+@pytest.mark.parametrize("kind", ["espcn", "srcnn", "edsr", "resdeconv"])
+def test_input_gradients_of_the_cascade_networks(kind):
+    """The reference modules are ordinary autograd graphs (espcn.py:46-51, resdeconv.py:164-195): an end-to-end cascade fine-tune
+    needs the gradient w.r.t. each network's INPUT too.  fp32 against the oracle: first-layer 5x5 / 9x9 / 3x3 stride-1 input
+    gradients and the 7x7 stride-2 stem's (four parity classes of 3 / 4 taps per axis), odd-ish sizes."""
+    from srcgan_amd import ESPCN, SRCNN, EDSR, ResDeconv, MSELoss
+    torch.manual_seed(17)
+    if kind == "espcn":
+        net, fwd, x, up = ESPCN(3, 3, 2, dtype="fp32"), lambda sd, t: oracle.espcn_forward(sd, t, 2), torch.rand(2, 3, 20, 28), 2
+    elif kind == "srcnn":
+        net, fwd, x, up = SRCNN(1, 1, 2, dtype="fp32"), lambda sd, t: oracle.srcnn_forward(sd, t), torch.rand(2, 1, 21, 30), 1
+    elif kind == "edsr":
+        net, fwd, x, up = EDSR(3, 3, 2, num_residuals=2, dtype="fp32"), lambda sd, t: oracle.edsr_forward(sd, t), torch.rand(1, 3, 18, 22), 2
+    else:
+        net, fwd, x, up = ResDeconv(3, 3, dtype="fp32"), lambda sd, t: oracle.resdeconv_forward(sd, t), torch.rand(2, 3, 48, 32), 1
+    net = net.cuda()
+    sd = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in net.named_parameters()}
+    t = torch.rand(x.shape[0], 3 if kind != "srcnn" else 1, x.shape[2] * up, x.shape[3] * up)
+    xr = x.clone().requires_grad_(True)
+    oracle.mse_loss(fwd(sd, xr), t).backward()
+    xg = x.cuda().requires_grad_(True)
+    MSELoss()(net(xg), t.cuda()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < F32_TOL
+    for k, p in net.named_parameters():
+        if float(sd[k].grad.abs().max()) > 1e-7:
+            assert rel_err(p.grad.cpu(), sd[k].grad) < F32_TOL, k
+
+
 def test_empty_batch_generator():
     """An empty batch gives an empty output of the right shape and zero parameter gradients (aten::convolution's behaviour on
     the reference side), not a kernel launch."""
