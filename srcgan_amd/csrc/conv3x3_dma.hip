@@ -309,13 +309,44 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         uty = __builtin_amdgcn_readfirstlane(uty); ub = __builtin_amdgcn_readfirstlane(ub);
         dct = __builtin_amdgcn_readfirstlane(dct); dtx = __builtin_amdgcn_readfirstlane(dtx);
         dty = __builtin_amdgcn_readfirstlane(dty); db = __builtin_amdgcn_readfirstlane(db);
-        auto advance = [&]() {
-            uct += dct; if (uct >= p.ctiles) { uct -= p.ctiles; ++utx; }
-            utx += dtx; if (utx >= p.tiles_x) { utx -= p.tiles_x; ++uty; }
-            uty += dty; if (uty >= p.tiles_y) { uty -= p.tiles_y; ++ub; }
-            ub += db;
+        auto advance_st = [&](int& ct_, int& tx_, int& ty_, int& b_) __attribute__((always_inline)) {
+            ct_ += dct; if (ct_ >= p.ctiles) { ct_ -= p.ctiles; ++tx_; }
+            tx_ += dtx; if (tx_ >= p.tiles_x) { tx_ -= p.tiles_x; ++ty_; }
+            ty_ += dty; if (ty_ >= p.tiles_y) { ty_ -= p.tiles_y; ++b_; }
+            b_ += db;
         };
+        auto advance = [&]() { advance_st(uct, utx, uty, ub); };
+        // L2 prefetch pointer (SG_PF): one chunk ahead of the issue pointer.  A stage's landing takes 2.3-2.7 us beside the MFMA
+        // waves (HBM latency under load) and only NSTG - 1 stages can be in flight per CU -- 40 KiB / 2.5 us = 16 GB/s per CU =
+        // 4.1 TB/s chip-wide, the rate the Cout = 32 convolutions run at.  A 4-byte-per-lane LDS-DMA of the SAME per-lane offsets
+        // into a 256-byte dummy region touches every 64-byte line of the chunk after the one being issued: its HBM latency
+        // overlaps the current landings, and the real DMA of that chunk then reads L2.
+        // MEASURED (round 2, scripts/microbench_conv.py, blocked layout): with the prefetch 64->32 50.8 -> 53.8 us, 128->32 83.5 -> 88.4,
+        // 160->32 111 -> 118, 192->64 239 -> 246: 3-7 % SLOWER.  More bytes in flight towards HBM do not help: the landing rate
+        // is set on the CU side of L2 (LDS-DMA ingest beside the MFMA waves' LDS traffic), not by HBM latency.  Off by default.
+#ifndef SG_PF
+#define SG_PF 0
+#endif
+        int pct = uct, ptx = utx, pty = uty, pb = ub;
         const char* xb0 = (const char*)p.x + chan_off<T>(p.xcoff, p.xplane);
+        char* const pf_dummy = smem + bias_off + ((p.ctiles * COT * 4 + 255) & ~255);
+        auto prefetch = [&](int c) __attribute__((always_inline)) {                       // chunk c of the unit (pct, ptx, pty, pb): lines -> L2
+            const long org = ((long)(p.rev ? p.B - 1 - pb : pb) * p.H + (pty * TH - p.pad_y)) * p.W + (ptx * TW - p.pad_x);
+            const char* bx = xb0 + org * p.xpix + c * cstride;
+            const int cls = (pty == 0 ? 0 : pty == p.tiles_y - 1 ? 2 : 1) * 3 + (ptx == 0 ? 0 : ptx == p.tiles_x - 1 ? 2 : 1);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)bx, 0, nrec, 0x00020000);
+#define SG_PF_CLASS(K)                                                                                \
+            case K:                                                                                   \
+                _Pragma("unroll") for (int it = 0; it < HIT; ++it)                                     \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)pf_dummy, 4, tab##K[it], 0, 0, 0); \
+                asm volatile("; prefetch class " #K);                                                 \
+                break;
+            switch (cls) {
+                SG_PF_CLASS(0) SG_PF_CLASS(1) SG_PF_CLASS(2) SG_PF_CLASS(3) SG_PF_CLASS(4)
+                SG_PF_CLASS(5) SG_PF_CLASS(6) SG_PF_CLASS(7) SG_PF_CLASS(8)
+            }
+#undef SG_PF_CLASS
+        };
         auto issue = [&](int c, int stage) __attribute__((always_inline)) {             // chunk c of the unit (uct, utx, uty, ub)
             char* lh = smem + stage * SBYTES;
             char* lw = lh + HBYTES;
@@ -360,9 +391,22 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             if (++ac == p.nchunk) { ac = 0; au += gw; if (au < u_hi) advance(); }
             return true;
         };
-        bool ahead = true;
+        // prefetch pointer: (pc, pu) with its own unit decode, always one chunk ahead of (ac, au)
+        int pc = 0, pu = u0;
+        auto pf_step = [&]() __attribute__((always_inline)) { if (++pc == p.nchunk) { pc = 0; pu += gw; if (pu < u_hi) advance_st(pct, ptx, pty, pb); } };
+        auto pf_next = [&]() __attribute__((always_inline)) {          // false when nothing is left to prefetch
+            if (!SG_PF || pu >= u_hi) return false;
+            prefetch(pc);
+            pf_step();
+            return true;
+        };
+        // prologue in the steady-state order -- DMA(0), PF(1), [DMA(1), PF(2)] -- so that the counted wait below holds from the
+        // first chunk on: behind the pieces of chunk c come HIT prefetch pieces per later stage and the later stages' own pieces
+        bool ahead = issue_next(), pfd = false;
+        pf_step();
 #pragma unroll
-        for (int k = 0; k < NSTG - 1; ++k) ahead = issue_next();
+        for (int k = 1; k < NSTG - 1; ++k) { pfd = pf_next(); ahead = issue_next(); }
+        pfd = pf_next();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the LDS bias copy
         [[maybe_unused]] int trk = 0;
         for (int u = u0; u < u_hi; u += gw) {
@@ -374,13 +418,20 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #endif
                 // my pieces of this chunk's stage landed; MFMA waves left the stage that is issued next.  With 3 stages the
                 // newest stage (HIT pieces per wave, issued last, completing in order) may still be in flight.
-                if (NSTG == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(HIT) : "memory");
+                // (vmcnt retires in order: what may stay in flight is everything issued AFTER this chunk's pieces -- per later
+                //  stage its HIT(+WIT) pieces and the HIT prefetch pieces that followed it)
+                if (SG_PF) {
+                    // pfd: the prefetch issued last exists, hence every piece of the steady-state pattern behind chunk c does
+                    if (pfd) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NSTG == 3 ? 3 * HIT + WIT * (WRES ? 0 : 1) : HIT) : "memory");
+                    else sg_barrier_dma();                               // tail of the stream: wait for everything
+                } else if (NSTG == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(HIT) : "memory");
                 else sg_barrier_dma();
 #ifdef SG_TRACE
                 const unsigned long long t_bar = __builtin_amdgcn_s_memrealtime();
 #endif
                 if (SG_DBG(p, 2)) continue;
                 ahead = issue_next();
+                pfd = pf_next();
 #ifdef SG_TRACE
                 if (p.trace && blockIdx.x == 8 && iw == 0 && lane == 0 && trk < 60) {
                     p.trace[trk * 8 + 0] = t_land; p.trace[trk * 8 + 1] = t_bar; p.trace[trk * 8 + 2] = __builtin_amdgcn_s_memrealtime(); ++trk;
@@ -529,7 +580,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG = 2, int PT = 2>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
-    constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096;        // + bias copy (<= 1024 output channels)
+    constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096 + 256;  // + bias copy (<= 1024 output channels) + prefetch dummy
     static_assert(NSTG == 2 || WRES, "three stages only beside resident weights");
     auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG, PT>;
     static bool attr_set = false;
