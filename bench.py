@@ -195,6 +195,7 @@ def pmc_traffic(cls):
         data = json.load(open(files[-1]))["kernels"]
     except Exception:
         return None
+    pmc_traffic.source = os.path.relpath(files[-1], ROOT)
     m = re.match(r"(\w+)<(\w+),(.*)>", cls)
     if not m:
         return None
@@ -414,6 +415,8 @@ def main():
             roofline = {"bound": "mfma", "kernel": k["cls"], "launches": k["count"], "avg_ms": k["ms"] / k["count"],
                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                         "traffic": pmc_traffic(k["cls"]) if args.config == "paired" else None,
+                        "traffic_source": (getattr(pmc_traffic, "source", None) or "none") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command, scripts/profile_round.sh; counters cannot be read inside the timed process)",
                         "algorithmic_bytes_per_launch": k["bytes"] / k["count"],
                         "algorithmic_gbytes_per_s": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
     barrier()
