@@ -641,6 +641,13 @@ static int dispatch_wd(const WdP& p, int mt, int nt, hipStream_t st, int& nsplit
                 case 2: rc = launch_wd<T, 2, 4, 4>(p, st); break;
             }
         }
+    } else if (nt == 3) {
+        if constexpr (!F) {
+            switch (mt) {
+                case 1: rc = launch_wd<T, 1, 3, 4>(p, st); break;
+                case 2: rc = launch_wd<T, 2, 3, 4>(p, st); break;
+            }
+        }
     } else
     switch (mt) {
         case 1: rc = launch_wd<T, 1, 2, F ? 2 : 4>(p, st); break;
@@ -656,7 +663,8 @@ static int dispatch_wd(const WdP& p, int mt, int nt, hipStream_t st, int& nsplit
 // Input-channel tiles per workgroup: a row group of <= 64 gradient channels takes 4 (128 input channels, 8 waves)
 // instead of 2 -- the 2x2-wave form left one wave per SIMD (640 TFLOP/s against 1000 for the 4x2 form) and staged
 // the gradient planes once per 64 input channels.
-static int wd_nt(int mt, int cin_max, int dtype) { return (sg_is16(dtype) && mt <= 2 && cin_max > 64) ? 4 : 2; }
+// (3 when 96 input channels suffice -- the (dy2, dy1) row group of a dense block: 55 instead of 68 KiB staged per tile step)
+static int wd_nt(int mt, int cin_max, int dtype) { return (sg_is16(dtype) && mt <= 2 && cin_max > 64) ? (cin_max <= 96 ? 3 : 4) : 2; }
 
 // pixel splits per row group: fill the chip once (workgroups resident per CU follow from the LDS tile)
 static int wd_nsplit(int mt, int nt, int ncit, int dtype, int B, int H, int W) {
@@ -675,7 +683,7 @@ extern "C" size_t srcgan_wgrad_dense_slab_bytes(int G, int C, int dtype, int B, 
     size_t mx = 0;
     for (int g_base = 0; g_base < G; g_base += 128) {
         const int rows = G - g_base < 128 ? G - g_base : 128, mt = cdiv(rows, 32);
-        for (int nt = 2; nt <= (sg_is16(dtype) && mt <= 2 ? 4 : 2); nt += 2) {                 // either column-tile form may be chosen at run time
+        for (int nt = 2; nt <= (sg_is16(dtype) && mt <= 2 ? 4 : 2); ++nt) {                    // any column-tile form may be chosen at run time
             const int ncit = cdiv(C, 32 * nt);
             const size_t b = (size_t)wd_nsplit(mt, nt, ncit, dtype, B, H, W) * ncit * 10 * (32 * mt) * (32 * nt) * sizeof(float);
             if (b > mx) mx = b;
@@ -737,6 +745,7 @@ extern "C" int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream
                                             q.seg[k].bias = d->seg[k].bias; q.seg[k].Cin = d->seg[k].Cin; q.seg[k].alpha = d->seg[k].alpha; }
         const long per_split = (long)p.ncit * 10 * q.COT * 32 * nt;
         if (nt == 4) hipLaunchKernelGGL(wgrad_dense_reduce_k<128>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
+        else if (nt == 3) hipLaunchKernelGGL(wgrad_dense_reduce_k<96>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
         else hipLaunchKernelGGL(wgrad_dense_reduce_k<64>, dim3((unsigned)cdivl(per_split, 64)), dim3(256), 0, st, q);
         SG_LAUNCH_CHECK();
     }
