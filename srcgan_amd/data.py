@@ -3,6 +3,8 @@
 * Colour conversions of ``dataset.Basic`` (src/dataset.py:114-159) behind ``G2RGB`` / ``G2LAB.__getitem__`` (:179-199, :234-254):
   8-bit RGB -> the float tensors of a training batch, on the device and for a whole batch at once (the reference converts one
   sample at a time on the host with scikit-image).  Same method names as the reference (``_arr2gray`` -> ``arr2gray`` ...).
+* The folder datasets themselves (``Basic`` / ``G2RGB`` / ``G2LAB`` / ``load_dataset``, dataset.py:27-285): list file, PIL
+  decode and the optional transform on the host (DataLoader workers), conversion per batch on the device (``DeviceLoader``).
 * ``.pth`` naming and round trip: ``{SRModel}_A2C_x{up}_{epoch:04d}.pth`` / ``{CModel}_C2B_x{up}_{epoch:04d}.pth`` written
   every 25 epochs (src/trainCas.py:221-225) and parsed back by the test script to rebuild the two networks
   (src/testCas.py:41-56).  Files hold ``torch.save(net.state_dict())`` with the reference's key names, so they load into
@@ -13,11 +15,20 @@ There is no CPU fallback: the conversions run in libsrcgan_amd.so (csrc/colour.h
 from __future__ import annotations
 
 import os
-from typing import Dict, Tuple
+from typing import Callable, Dict, Iterator, Optional, Tuple
 
 import torch
+import torch.utils.data
 
 from . import _native as N
+
+# dataset.py:24-25 resolves '../dataset/' next to its source file.  Here, in this order: the ``dataset_dir`` argument, this
+# module attribute when set, $SRCGAN_DATASET_DIR, ./dataset of the working directory.
+DATASET_DIR: Optional[str] = None
+
+
+def _dataset_dir(arg: Optional[str]) -> str:
+    return arg or DATASET_DIR or os.environ.get("SRCGAN_DATASET_DIR") or os.path.join(os.getcwd(), "dataset")
 
 _MODES = {"gray": (0, 1), "rgb": (1, 3), "lab": (2, 3), "ab": (3, 2)}
 
@@ -75,21 +86,132 @@ def ab2img(l: torch.Tensor, ab: torch.Tensor) -> torch.Tensor:
     return lab2img(torch.cat([l, ab], dim=-3))
 
 
-class G2RGB:
-    """Batch form of ``dataset.G2RGB.__getitem__`` (dataset.py:179-199) for arrays already decoded to 8-bit RGB:
-    src -> tensor(L), tar -> tensor(RGB).  ``src_ch`` / ``tar_ch`` / ``ver`` as the reference's attributes (:174-176)."""
+class Basic(torch.utils.data.Dataset):
+    """``dataset.Basic`` (dataset.py:27-47): ``<dataset_dir>/<root>/<split>.txt`` lists one file name per line, the images
+    live in ``<root>/src/<name>`` and ``<root>/tar/<name>``.  The division of labour differs from the reference's: a sample is
+    the DECODED 8-bit pair (the PIL decode + the optional ``transform`` stay in the DataLoader workers, on the host), the
+    colour conversion is done once per batch on the device by :meth:`to_device` / :class:`DeviceLoader`, which yield the
+    ``{"src", "tar", "idx"}`` float batch the reference's ``DataLoader`` yields.  ``root=None`` gives a converter without a
+    file list (``G2LAB()(src_u8, tar_u8)``).
+
+    ``transform`` follows the reference's contract (:183-190): called with ``{'src': PIL.Image, 'tar': PIL.Image}``, returns
+    the same dict holding arrays ([H,W,3] uint8) -- the reference ships no transform of its own."""
+    src_ch, tar_ch, ver = 1, 3, "Basic"
+    _tar_mode = "rgb"
+
+    def __init__(self, root: Optional[str] = None, split: str = "all", transform: Optional[Callable] = None,
+                 dataset_dir: Optional[str] = None):
+        self.root, self.split, self.transform = root, split, transform
+        self.datalist = []
+        if root is None:
+            return
+        base = os.path.join(_dataset_dir(dataset_dir), root)
+        with open(os.path.join(base, "{}.txt".format(split)), "r") as f:        # a missing list raises, as in the reference
+            self.datalist = [line.strip() for line in f.readlines()]
+        self.srcpath = os.path.join(base, "src", "%s")
+        self.tarpath = os.path.join(base, "tar", "%s")
+
+    def __len__(self) -> int:
+        return len(self.datalist)
+
+    @staticmethod
+    def _decode(path: str):
+        from PIL import Image
+        return Image.open(path).convert("RGB")
+
+    def __getitem__(self, idx: int) -> Dict[str, object]:
+        """Host half of ``G2RGB.__getitem__`` (dataset.py:179-190): decode, transform; uint8 [H,W,3] tensors + the index."""
+        import numpy as np
+        name = self.datalist[idx]
+        sample = {"src": self._decode(self.srcpath % name), "tar": self._decode(self.tarpath % name)}
+        if self.transform:
+            sample = self.transform(sample)
+        out = {}
+        for k in ("src", "tar"):
+            a = np.array(sample[k])                                    # a copy: PIL's buffer is read-only
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[-1] != 3:
+                raise ValueError(f"{self.ver}[{idx}]: '{k}' must be an 8-bit [H,W,3] array after the transform, got {a.dtype} {a.shape}")
+            out[k] = torch.from_numpy(a)
+        out["idx"] = idx
+        return out
+
+    def __call__(self, src: torch.Tensor, tar: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Device half (dataset.py:191-194 / :246-249): src -> tensor(L), tar -> tensor(RGB | LAB), whole batch at once."""
+        return {"src": arr2gray(src), "tar": _convert(tar, self._tar_mode)}
+
+    def to_device(self, batch: Dict[str, object], device="cuda") -> Dict[str, object]:
+        """A collated batch of :meth:`__getitem__` samples (uint8 [B,H,W,3] on the host) -> the reference's batch on the device."""
+        out = self(batch["src"].to(device, non_blocking=True), batch["tar"].to(device, non_blocking=True))
+        out["idx"] = batch["idx"]
+        return out
+
+    @staticmethod
+    def _whitespace(img: torch.Tensor, width: int = 5) -> torch.Tensor:
+        """dataset.py:58-66: a white frame of ``width`` pixels around a uint8 [H,W,C] image."""
+        row, col, ch = img.shape
+        out = torch.full((row + 2 * width, col + 2 * width, ch), 255, dtype=torch.uint8, device=img.device)
+        out[width:row + width, width:col + width] = img
+        return out
+
+    def show(self, idx: int, save_dir: Optional[str] = None) -> str:
+        """``G2RGB.show`` / ``G2LAB.show`` (dataset.py:201-215, :256-272): source | target side by side, both framed, written
+        to ``<save_dir>/<split>-<idx>.png`` (default ``./example/<root><ver>``).  A source of another size is resized to the
+        target's with PIL's bilinear filter (the reference calls cv2.resize, which is not installed here: not pixel-pinned)."""
+        import numpy as np
+        from PIL import Image
+        s = self[idx]
+        b = self(s["src"].cuda(), s["tar"].cuda())
+        src = (b["src"].expand(3, -1, -1).permute(1, 2, 0) * 255).to(torch.uint8)          # _rgb2img of a 1-channel array
+        tar = lab2img(b["tar"]) if self._tar_mode == "lab" else (b["tar"].permute(1, 2, 0) * 255).to(torch.uint8)
+        src, tar = self._whitespace(src).cpu().numpy(), self._whitespace(tar).cpu().numpy()
+        if src.shape[:2] != tar.shape[:2]:
+            src = np.asarray(Image.fromarray(src).resize(tar.shape[:2][::-1], Image.BILINEAR))
+        save_dir = save_dir or os.path.join("example", "{}{}".format(self.root, self.ver))
+        os.makedirs(save_dir, exist_ok=True)
+        path = "{}/{}-{}.png".format(save_dir, self.split, idx)
+        Image.fromarray(np.concatenate([src, tar], axis=1)).save(path)
+        return path
+
+
+class G2RGB(Basic):
+    """``dataset.G2RGB`` (dataset.py:160-215): src -> tensor(L), tar -> tensor(RGB).  ``src_ch`` / ``tar_ch`` / ``ver`` as the
+    reference's attributes (:174-176)."""
     src_ch, tar_ch, ver = 1, 3, "G2RGB"
-
-    def __call__(self, src: torch.Tensor, tar: torch.Tensor) -> Dict[str, torch.Tensor]:
-        return {"src": arr2gray(src), "tar": arr2rgb(tar)}
+    _tar_mode = "rgb"
 
 
-class G2LAB:
-    """Batch form of ``dataset.G2LAB.__getitem__`` (dataset.py:234-254): src -> tensor(L), tar -> tensor(LAB)."""
+class G2LAB(Basic):
+    """``dataset.G2LAB`` (dataset.py:217-272): src -> tensor(L), tar -> tensor(LAB)."""
     src_ch, tar_ch, ver = 1, 3, "G2LAB"
+    _tar_mode = "lab"
 
-    def __call__(self, src: torch.Tensor, tar: torch.Tensor) -> Dict[str, torch.Tensor]:
-        return {"src": arr2gray(src), "tar": arr2lab(tar)}
+
+def load_dataset(root: str, ver: str = "G2RGB", mode: str = "training", dataset_dir: Optional[str] = None):
+    """``dataset.load_dataset`` (dataset.py:275-285): the train / val / test splits of one dataset version (``mode`` is unused
+    there too)."""
+    kinds = {"G2RGB": G2RGB, "G2LAB": G2LAB}
+    if ver not in kinds:
+        raise KeyError(f"load_dataset: unknown version {ver!r} (known: {sorted(kinds)})")
+    return tuple(kinds[ver](root=root, split=s, dataset_dir=dataset_dir) for s in ("train", "val", "test"))
+
+
+class DeviceLoader:
+    """``DataLoader(dataset, batch_size, num_workers=..., shuffle=..., drop_last=...)`` of trainCas.py:176-178 / testCas.py:61-62
+    whose batches arrive converted on the device: the workers decode into pinned uint8 batches ([B,H,W,3], 3 bytes per pixel
+    over PCIe instead of the 16 the reference's float32 src + tar carry), ``dataset.to_device`` converts each batch in one
+    launch per tensor.  Iterating yields ``{"src": [B,1,H,W], "tar": [B,3,H,W], "idx": [B]}``."""
+
+    def __init__(self, dataset: Basic, batch_size: int = 1, device="cuda", **kw):
+        kw.setdefault("pin_memory", torch.cuda.is_available())
+        self.dataset, self.device = dataset, device
+        self.loader = torch.utils.data.DataLoader(dataset, batch_size, **kw)
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def __iter__(self) -> Iterator[Dict[str, object]]:
+        for batch in self.loader:
+            yield self.dataset.to_device(batch, self.device)
 
 
 # ---------------------------------------------------------------------------------------------------------------- checkpoints

@@ -64,3 +64,28 @@ def test_bad_inputs_are_refused():
         D.arr2rgb(torch.zeros(4, 4, 4, dtype=torch.uint8, device="cuda"))
     with pytest.raises(ValueError):
         D.lab2img(torch.zeros(2, 4, 4, device="cuda"))
+
+
+def test_folder_dataset_device_batches(tmp_path):
+    """dataset.G2LAB / G2RGB behind a DataLoader (testCas.py:44,61-62): files on disk -> the {'src','tar','idx'} batch on the
+    device, equal to the oracle's per-sample ``__getitem__`` maths on the decoded arrays; ``show`` writes the framed pair."""
+    from PIL import Image
+    from srcgan_amd import data as D
+    from test_host_logic import _make_folder_dataset
+    names, arrays = _make_folder_dataset(tmp_path, n=5, hw=(12, 16), up=2)
+    for ver, conv in (("G2LAB", O.arr2lab), ("G2RGB", O.arr2rgb)):
+        train, _, test = D.load_dataset("Mini", ver, dataset_dir=str(tmp_path))
+        seen = 0
+        for batch in D.DeviceLoader(train, 2, num_workers=2, shuffle=False, drop_last=False):
+            assert batch["src"].is_cuda and batch["src"].shape[1:] == (1, 12, 16) and batch["tar"].shape[1:] == (3, 24, 32)
+            for j, idx in enumerate(batch["idx"].tolist()):
+                src, tar = arrays[names[idx]]
+                assert float((batch["src"][j].cpu() - O.arr2gray(src)).abs().max()) <= 2e-7
+                assert float((batch["tar"][j].cpu() - conv(tar)).abs().max()) <= 2e-7
+                seen += 1
+        assert seen == 3
+        path = test.show(0, save_dir=str(tmp_path / "example"))
+        img = np.asarray(Image.open(path))
+        assert img.shape == (24 + 10, 2 * (32 + 10), 3) and (img[:5] == 255).all() and (img[:, :5] == 255).all()
+        if ver == "G2RGB":                                                       # right half = the target inside its frame
+            assert np.array_equal(img[5:-5, 42 + 5:-5], arrays[names[4]][1])

@@ -232,3 +232,49 @@ def test_bench_launcher_reports_a_failed_rank():
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "MI355X" in out.stderr
+
+
+# ------------------------------------------------------------------------------------------------ folder datasets (dataset.py)
+def _make_folder_dataset(tmp_path, n=5, hw=(12, 16), up=1):
+    """A miniature '<root>/{train,val,test}.txt + src/ + tar/' tree in the reference's layout (dataset.py:39-45)."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    root = tmp_path / "Mini"
+    (root / "src").mkdir(parents=True), (root / "tar").mkdir()
+    arrays = {}
+    names = ["im%02d.png" % i for i in range(n)]
+    for nm in names:
+        tar = rng.integers(0, 256, (hw[0] * up, hw[1] * up, 3), dtype=np.uint8)
+        src = rng.integers(0, 256, (hw[0], hw[1]), dtype=np.uint8)              # a grey file: .convert('RGB') replicates it
+        Image.fromarray(src).save(root / "src" / nm), Image.fromarray(tar).save(root / "tar" / nm)
+        arrays[nm] = (np.stack([src] * 3, -1), tar)
+    (root / "train.txt").write_text("\n".join(names[:3]) + "\n")
+    (root / "val.txt").write_text(names[3] + "\n")
+    (root / "test.txt").write_text("  " + names[4] + "  \n")                    # lines are stripped (dataset.py:42)
+    return names, arrays
+
+
+def test_folder_dataset_lists_and_decodes(tmp_path):
+    from srcgan_amd import data as D
+    names, arrays = _make_folder_dataset(tmp_path)
+    train, val, test = D.load_dataset("Mini", "G2LAB", dataset_dir=str(tmp_path))
+    assert (len(train), len(val), len(test)) == (3, 1, 1) and train.ver == "G2LAB" and (train.src_ch, train.tar_ch) == (1, 3)
+    assert isinstance(train, torch.utils.data.Dataset) and isinstance(train, D.Basic)
+    for ds, idx, nm in ((train, 2, names[2]), (test, 0, names[4])):
+        s = ds[idx]
+        assert s["idx"] == idx and s["src"].dtype == torch.uint8
+        assert np.array_equal(s["src"].numpy(), arrays[nm][0]) and np.array_equal(s["tar"].numpy(), arrays[nm][1])
+    # the transform contract of dataset.py:183-190: PIL images in, arrays out
+    flip = lambda smp: {k: np.asarray(v)[:, ::-1] for k, v in smp.items()}
+    ds = D.G2RGB("Mini", "train", transform=flip, dataset_dir=str(tmp_path))
+    assert np.array_equal(ds[0]["tar"].numpy(), arrays[names[0]][1][:, ::-1])
+    with pytest.raises(ValueError):
+        D.G2RGB("Mini", "train", transform=lambda smp: {k: np.asarray(v, np.float32) for k, v in smp.items()}, dataset_dir=str(tmp_path))[0]
+    with pytest.raises(FileNotFoundError):
+        D.G2RGB("Mini", "all", dataset_dir=str(tmp_path))                       # no all.txt in the tree
+    with pytest.raises(KeyError):
+        D.load_dataset("Mini", "G2XYZ", dataset_dir=str(tmp_path))
+    # host-side batching is plain DataLoader collation of the decoded pairs
+    batch = next(iter(torch.utils.data.DataLoader(train, 3)))
+    assert batch["src"].shape == (3, 12, 16, 3) and batch["src"].dtype == torch.uint8 and batch["idx"].tolist() == [0, 1, 2]
+    assert len(D.G2LAB()) == 0                                                   # converter form: no file list
