@@ -21,7 +21,17 @@
 
 #include "conv_params.h"
 
+// Cost-removal switches of this kernel's hot loop (scripts/microbench_generic.py): only in a -DSG_DIAG -DSG_IG_DIAG variant --
+// as run-time branches they stop the compiler from hoisting fragment reads over MFMAs, so even other SG_DIAG variants leave them out.
+#if defined(SG_DIAG) && defined(SG_IG_DIAG)
+#define IG_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define IG_DBG(p, bit) 0
+#endif
 
+
+// Occupancy: hipcc takes 188 registers for the 64-accumulator forms (2 workgroups per CU).  Capping them at 168 (3 per CU,
+// __launch_bounds__(256, 3)) changed neither the kernels' times nor the training step (same-box A/B, round 2).
 template <typename T, int KH, int KW, int S, int MT, int PT, bool WPK>
 __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     using D = DT<T>;
@@ -89,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     auto issue_halo = [&](int c, auto rs) {
         constexpr int R = decltype(rs)::value;
         const bool cok = c * D::KCE + part * D::EPP < p.Cin;
+        if (IG_DBG(p, 2) && c > 0) return;            // diagnostic builds: operand traffic of the first chunk only
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
             const int off = (h_goff[it] >= 0 && cok) ? h_goff[it] + c * 64 : 0;
@@ -108,6 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     };
     auto issue_w = [&](int c, auto rs) {
         constexpr int R = decltype(rs)::value;
+        if (IG_DBG(p, 8) && c > 0) return;            // diagnostic builds: weight traffic of the first chunk only
         if constexpr (!WPK) {
             const char* ws = wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     // barriers (it was: 16 MFMAs per wave against a 1-2 us load, matrix pipe 22 % busy on the 4x4 stride-2 layers).
     u32x4 wv[WPK ? WIT : 1];
     auto issue_wrow = [&](int c, int ky) {
+        if (IG_DBG(p, 8) && (c > 0 || ky > 0)) return;
         if constexpr (WPK) {
             const char* ws = wb + ((size_t)c * NTAP + (size_t)ky * KW) * COT * 64;
 #pragma unroll
@@ -156,9 +169,11 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     using RS1 = std::integral_constant<int, NRS - 1>;
     auto chunk = [&](int c, auto rs) {
         // registers (chunk c) -> LDS; the previous chunk's readers passed the barrier at the end of the previous call
-        write_halo(c, rs);
-        write_w(rs);
-        write_wrow();                 // kernel row 0 of this chunk
+        if (!(IG_DBG(p, 16) && c > 0)) {
+            write_halo(c, rs);
+            write_w(rs);
+            write_wrow();             // kernel row 0 of this chunk
+        }
         __syncthreads();
         if (c + NRS < p.nchunk) {     // prefetch into the registers just drained: in flight while NRS chunks' MFMAs run
             issue_halo(c + NRS, rs);
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
             if constexpr (WPK) {
                 if (ky > 0) {
                     __syncthreads();  // the previous row's readers are done
-                    write_wrow();
+                    if (!IG_DBG(p, 16)) write_wrow();
                     __syncthreads();
                 }
                 if (ky + 1 < KH) issue_wrow(c, ky + 1);
@@ -198,17 +213,34 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
                                     acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bb[q][j], acc[m][q], 0, 0, 0);
                     } else {
                         bf16x8 a[MT], bb[PT];
+                        if (!IG_DBG(p, 32)) {
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            a[m] = *(const bf16x8*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
+                            for (int m = 0; m < MT; ++m)
+                                a[m] = *(const bf16x8*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
 #pragma unroll
-                        for (int q = 0; q < PT; ++q)
-                            bb[q] = *(const bf16x8*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
+                            for (int q = 0; q < PT; ++q)
+                                bb[q] = *(const bf16x8*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
+                        } else {
+                            const u32x4 stale = {0x3f803f80u ^ (unsigned)lane, 0x3f003f00u, 0x3e803e80u ^ (unsigned)c, 0x3f803f80u};
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) a[m] = __builtin_bit_cast(bf16x8, stale);
+#pragma unroll
+                            for (int q = 0; q < PT; ++q) bb[q] = __builtin_bit_cast(bf16x8, stale);
+                        }
+                        if (IG_DBG(p, 1)) {              // keep the fragment reads alive without the matrix pipe
+                            u32x4 t = {0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) t ^= __builtin_bit_cast(u32x4, a[m]);
+#pragma unroll
+                            for (int q = 0; q < PT; ++q) t ^= __builtin_bit_cast(u32x4, bb[q]);
+                            acc[0][0][0] += __builtin_bit_cast(float, t[0] ^ t[1] ^ t[2] ^ t[3]);
+                        } else {
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
                             for (int q = 0; q < PT; ++q)
                                 acc[m][q] = sg_mfma16<T>(a[m], bb[q], acc[m][q]);
+                        }
                     }
                 }
             }
@@ -233,6 +265,17 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     // per pixel: those convolutions ran at 380 TFLOP/s, store-bound).  With 16-byte-aligned operands each wave transposes a
     // row of its tile through LDS (the stage buffers are free: every wave passed the loop's last barrier) and reads it back
     // with the lanes of a pixel contiguous: 128-byte segments per pixel for residual / mask loads and the store.
+    if (IG_DBG(p, 4)) {                               // diagnostic builds: no epilogue (keep the accumulators alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) keep += acc[m][q][i];
+        if (keep == 1.2345e-30f) *(float*)p.y = keep;
+        return;
+    }
     if (p.vec16) {
         constexpr int RS = COT * 4 + 16;
         char* lw = smem + wave * 32 * RS;
@@ -260,6 +303,7 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     q.tiles_x = cdiv(p.OW, TW);
     q.tiles_y = cdiv(p.OH, TH);
     q.ctiles = ctiles;
+    { static const char* e = sg_env("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
     dim3 grid((unsigned)((size_t)q.tiles_x * q.tiles_y * p.B * ctiles), 1, 1);
     char cls[96];
     snprintf(cls, sizeof(cls), "conv_igemm<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), KH, KW, S, MT);

@@ -172,13 +172,6 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
     constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP;
     constexpr int RS = COT * 4 + 16;
     const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
-            *(f32x4*)(lds_wave + r * RS + (m * 32 + 8 * g + 4 * h) * 4) = v;
-        }
     const int cpart = lane % LPP, c0 = cpart * EPP, co0 = ct * COT + c0;
     const bool cok = co0 < p.Cout;
     float bias[EPP];
@@ -189,8 +182,33 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         for (int i = 0; i < EPP; i += 4) { const f32x4 bv = *(const f32x4*)(p.bias + co0 + i); bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3]; }
     }
     const bool use_r1 = p.r1 && co0 < p.r1cend, use_r2 = p.r2 && co0 < p.r2cend, use_mz = p.mz && co0 >= p.mzc0;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    constexpr int NP = 32 / PPP;
+    // The first residual and the activation-mask operand of ALL passes of the row are requested here, before the transposition:
+    // loaded inside the pass loop each exposed one memory latency per pass (a stride-2 parity gradient 128 -> 64 channels with
+    // its LeakyReLU mask: 147 -> 136 us, 118 us without the mask; -DSG_EPI_PF=0, scripts/microbench_generic.py).
+#ifndef SG_EPI_PF
+#define SG_EPI_PF 1
+#endif
+    vecT r1v[NP], mzv[NP];
+    const bool rowok = cok && oy < p.OH;
+    const size_t rowpix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + p.ob;
 #pragma unroll
-    for (int pass = 0; pass < 32 / PPP; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
+        const int ox = ox0 + pass * PPP + lane / LPP;
+        const size_t opix = rowpix + (size_t)ox * p.os;
+        if (SG_EPI_PF && use_r1 && rowok && ox < p.OW) r1v[pass] = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
+        if (SG_EPI_PF && use_mz && rowok && ox < p.OW) mzv[pass] = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+            *(f32x4*)(lds_wave + r * RS + (m * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
         const int pix = pass * PPP + lane / LPP;
         const int ox = ox0 + pix;
         float v[EPP];
@@ -199,23 +217,26 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
             const f32x4 t = *(const f32x4*)(lds_wave + pix * RS + (c0 + i) * 4);
             v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
-        if (!cok || oy >= p.OH || ox >= p.OW) continue;
-        const size_t opix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + (size_t)ox * p.os + p.ob;
-        typedef __attribute__((ext_vector_type(EPP))) T vecT;
+        if (!rowok || ox >= p.OW) continue;
+        const size_t opix = rowpix + (size_t)ox * p.os;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (use_r1) { const vecT t = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
+        if (!SG_EPI_PF) {
+            if (use_r1) r1v[pass] = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
+            if (use_mz) mzv[pass] = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
+        }
+        if (use_r1) {
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
+            for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(r1v[pass][i]); }
         if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + opix * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane));
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (use_mz) { const vecT t = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
+        if (use_mz) {
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] *= (to_f(t[i]) > 0.f ? 1.f : p.mslope); }
+            for (int i = 0; i < EPP; ++i) v[i] *= (to_f(mzv[pass][i]) > 0.f ? 1.f : p.mslope); }
         vecT o;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
