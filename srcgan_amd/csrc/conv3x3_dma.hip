@@ -212,10 +212,15 @@ __device__ __forceinline__ void sg_barrier_raw() { asm volatile("s_barrier" ::: 
 
 // 16 B per lane, global -> LDS, through a raw buffer descriptor {base, num_records = nrec bytes}: lanes whose byte
 // offset is outside [0, nrec) write zeros (hardware range check).  `base`/`nrec`/`lds` must be wave-uniform.
+// AUX = cache policy bits of the instruction (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1).
+template <int AUX = 0>
 __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, lptr_t lds, int soff = 0) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, AUX);
 }
+#ifndef SG_HALO_AUX
+#define SG_HALO_AUX 0
+#endif
 
 // WRES: the packed weights of ALL K chunks stay resident in LDS (one DMA per workgroup at kernel start) and a stage
 // holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
@@ -358,7 +363,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #define SG_ISSUE_CLASS(K)                                                                             \
             case K:                                                                                   \
                 _Pragma("unroll") for (int it = 0; it < HIT; ++it)                                     \
-                    dma_buf16(bx, nrec, tab##K[it], (lptr_t)(lh + (it * NLW + iw) * 1024));            \
+                    dma_buf16<SG_HALO_AUX>(bx, nrec, tab##K[it], (lptr_t)(lh + (it * NLW + iw) * 1024));            \
                 asm volatile("; tile class " #K);   /* a distinct tail: cases merged by code sinking index the tables in scratch */ \
                 break;
             switch (cls) {

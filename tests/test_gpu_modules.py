@@ -133,6 +133,24 @@ def test_rddbnet_nb23_f32_vs_oracle():
     assert max(rel_l2(g[k], g64[k]) for k in g) < F32_TOL
 
 
+def test_rddbnet_nb23_reference_fixture_f32():
+    """Bench-depth generator against the REFERENCE's own results (tests/golden/rddbnet_nb23.npz: reference f32 and f64 runs of
+    RDDBNet(3,3,4) under its default initialisation, seed 0): the native fp32 path meets 1e-3 on the output and, on the input
+    gradient and all 697 parameter gradients, max(1e-3, 3 x the reference's own f32-vs-f64 error) -- 2.9e-3 for dx in the
+    reference itself at this depth."""
+    from srcgan_amd import RDDBNet, MSELoss
+    from test_oracle_golden import depth_case_check, depth_case_state
+    g = load_golden("rddbnet_nb23")
+    net = depth_case_state(g, RDDBNet).to("cuda")
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    loss = MSELoss()(y, torch.from_numpy(g["t"]).cuda())
+    loss.backward()
+    assert abs(float(loss) - float(g["loss64"])) < 1e-5
+    worst = depth_case_check(g, y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in net.named_parameters()})
+    print("nb=23 fp32 vs reference f64:", worst)
+
+
 def test_rddbnet_nb23_bf16_vs_oracle():
     """The benchmark's dtype at the benchmark's depth (measured values are printed: pytest -s).  Yardstick: the oracle with bf16
     STORAGE of activations and conv weights but f32 arithmetic and an exact f32 backward (oracle.storage) -- the best any bf16

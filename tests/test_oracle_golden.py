@@ -306,3 +306,59 @@ def test_colour_restatement_known_answers():
     im = rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)
     back = O.lab2img(O.arr2lab(im).numpy().transpose(1, 2, 0))
     assert np.abs(back.astype(int) - im.astype(int)).max() <= 1
+
+
+def _depth_probe(n, k):
+    return np.cos(np.arange(n, dtype=np.float64) * 0.37 + k)
+
+
+def depth_case_check(g, y, dx, grads, f32_tol=1e-3):
+    """Compare one evaluation of RDDBNet(3,3,4) at nb=23 (y, dx, {name: grad}) with the reference fixture rddbnet_nb23.npz.
+    The fixture holds the reference's float32 AND float64 results: through 345 LeakyReLUs the reference's own f32 input
+    gradient is 2.9e-3 from its f64 one, so gradients are gated against the EXACT result with the reference's own f32 error as
+    the yardstick: err <= max(f32_tol, 3 x |ref32 - ref64|).  Returns the worst observed figures."""
+    names = [str(n) for n in g["names"]]
+    assert rel_err(y, g["y64"]) < f32_tol
+    e_dx, ref_dx = rel_err(dx, g["dx64"]), rel_err(g["dx32"], g["dx64"])
+    assert e_dx < max(f32_tol, 3 * ref_dx), (e_dx, ref_dx)
+    gn = np.array([float(grads[n].double().norm()) for n in names])
+    gp = np.array([float(np.dot(grads[n].double().numpy().ravel(), _depth_probe(grads[n].numel(), i))) for i, n in enumerate(names)])
+    e_norm, ref_norm = np.abs(gn / g["gnorm64"] - 1).max(), np.abs(g["gnorm32"] / g["gnorm64"] - 1).max()
+    assert e_norm < max(f32_tol, 3 * ref_norm), (e_norm, ref_norm)
+    # projections: error relative to the gradient's norm x the probe's norm (the projection itself can be near zero)
+    scale = g["gnorm64"] * np.array([np.linalg.norm(_depth_probe(grads[n].numel(), i)) for i, n in enumerate(names)])
+    e_proj, ref_proj = (np.abs(gp - g["gproj64"]) / scale).max(), (np.abs(g["gproj32"] - g["gproj64"]) / scale).max()
+    assert e_proj < max(f32_tol, 3 * ref_proj), (e_proj, ref_proj)
+    worst_full = 0.0
+    for k, v in g.items():
+        if k.startswith("grad64/"):
+            n = k[len("grad64/"):]
+            e, ref = rel_err(grads[n], v), rel_err(g["grad32/" + n], v)
+            assert e < max(f32_tol, 3 * ref), (n, e, ref)
+            worst_full = max(worst_full, e)
+    return {"dx": e_dx, "ref_dx": ref_dx, "norm": e_norm, "proj": e_proj, "full": worst_full}
+
+
+def depth_case_state(g, module_cls):
+    """The fixture's network: the reference initialisation under torch.manual_seed(seed), verified by one checksum per parameter."""
+    torch.manual_seed(int(g["seed"]))
+    net = module_cls(3, 3, 4)
+    sums = np.array([float(p.detach().double().sum()) for p in net.parameters()])
+    assert [k for k, _ in net.named_parameters()] == [str(n) for n in g["names"]]
+    assert np.array_equal(sums, g["param_sum"]), "initialisation differs from the reference's under the same seed"
+    return net
+
+
+def test_rddbnet_nb23_reference_fixture():
+    """The oracle at the benchmark's depth (RDDBNet(3,3,4): nf=64, nb=23, gc=32) against the REFERENCE's own run
+    (tests/golden/make_golden_depth.py): same-seed initialisation, output, input gradient, all 697 parameter gradients."""
+    import srcgan_amd
+    g = load_golden("rddbnet_nb23")
+    net = depth_case_state(g, srcgan_amd.RDDBNet)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.rddbnet_forward(sd, x, 4)
+    loss = oracle.mse_loss(y, torch.from_numpy(g["t"]))
+    loss.backward()
+    assert rel_err(y, g["y32"]) < TOL and abs(float(loss.detach()) - float(g["loss32"])) < 1e-6
+    depth_case_check(g, y.detach(), x.grad, {k: v.grad for k, v in sd.items()})
