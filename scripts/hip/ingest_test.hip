@@ -1,0 +1,260 @@
+// Micro-benchmark of the loader-specialised convolution's skeleton on every CU: does an LDS-DMA stage land while 8 MFMA waves
+// read fragments from the other stage and feed the matrix pipe?  (the Cout = 32 convolutions take
+// 68 us where the operand stream alone takes 46 and the MFMA loop alone 48.)
+//   one workgroup per CU = 8 MFMA waves + NLW loader waves, NSTG stage buffers of SP KiB in LDS, one barrier per chunk;
+//   loaders: SP 1-KiB pieces per chunk (buffer_load_dwordx4 ... lds, per-lane offsets fixed, scalar offset advances through SRC);
+//   MFMA waves: per chunk NRD ds_read_b128 from the stage that has landed + NMF 32x32x16 bf16 MFMAs fed by them.
+// Template switches remove one stream at a time (no run-time branches in the loops).  Output: us per launch, TB/s, PFLOP/s.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// random bf16 values in (-0.5, 0.5): the matrix pipe's power (hence the clock) depends on the operand bits
+__global__ void fill_k(unsigned short* p, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        const float f = ((x & 0xffff) / 65536.0f - 0.5f);
+        p[i] = (unsigned short)(__builtin_bit_cast(unsigned, f) >> 16);
+    }
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void dma(const __amdgpu_buffer_rsrc_t r, int voff, int soff, lptr_t lds) {
+    if constexpr (WIDTH == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void bar_dma() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// DMA: loaders stream; RD: fragment reads; MF: MFMAs; NLW loader waves; NSTG stages; SP KiB per stage; NRD reads, NMF MFMAs per chunk
+template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH, int PAT, int EPI, int ORD, int RL>
+__global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_per_wg, int nchunk, float* sink, char* dst, int imask, long dmask) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int SB = SP * 1024;
+    constexpr int PPI = 1024 / (64 * WIDTH);        // instructions per KiB piece (1 for 16-byte lanes)
+    if (wave >= 8) {
+        const int iw = wave - 8;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)blockIdx.x * bytes_per_wg), 0, (int)bytes_per_wg, 0x00020000);
+        const int voff = lane * WIDTH;
+        // PAT 1: the convolution's operand pattern.  Source = 4 channel planes of [16][256][256] pixels x 64 B (67 MB each, "blocked"
+        // layout); a unit = 16x32-pixel tile, 4 chunks = its 18x34-pixel halo in each plane; 8 units per workgroup, the workgroups
+        // of an XCD walk a contiguous unit range (tiles along a row first).  Piece p of a stage = halo pixels 16p .. 16p+15.
+        // PAT 2: the same with tiles of 8x64 pixels (halo 10x66: rows twice as long).
+        constexpr int TW_ = PAT == 2 ? 64 : 32, TH_ = PAT == 2 ? 8 : 16, IW_ = TW_ + 2, IH_ = TH_ + 2, NPIX = IW_ * IH_;
+        constexpr int HP = (NPIX + 15) / 16;                 // KiB pieces of a halo stage (39 for 18x34, 42 for 10x66)
+        int tab[(HP + NLW - 1) / NLW];
+        if (PAT) {
+#pragma unroll
+            for (int j = 0; j < (HP + NLW - 1) / NLW; ++j) {
+                const int pix = (j * NLW + iw) * 16 + (lane >> 2);
+                const int iy = pix / IW_, ix = pix - iy * IW_;
+                tab[j] = pix < NPIX ? (iy * 256 + ix) * 64 + (lane & 3) * 16 : 0x7fffffff;      // beyond num_records: zero fill
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7ffffff0, 0x00020000);
+        const int ubase = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (nchunk >> 2);
+        const int ulo = (blockIdx.x & 7) * (gridDim.x >> 3) * (nchunk >> 2) + (blockIdx.x >> 3), ugw = gridDim.x >> 3;
+        auto issue = [&](int c) {
+            if (!DMA) return;
+            char* st = smem + (c % NSTG) * SB;
+            if (PAT) {
+                const int u = ORD ? ulo + (c >> 2) * ugw : ubase + (c >> 2), plane = c & 3;
+                constexpr int TX = 256 / TW_, TY = 256 / TH_;
+                const int tx = u % TX, ty = (u / TX) % TY, img = (u / (TX * TY)) & imask;
+                long org = (((long)img * 256 + ty * TH_ - 1) * 256 + tx * TW_ - 1) * 64;
+                if (org < 0) org = 0;
+                const char* b = src + (long)plane * (16L * 256 * 256 * 64) + org;
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, IH_ * 256 * 64, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < (HP + NLW - 1) / NLW; ++j)
+                    if (j * NLW + iw < HP) dma<16>(rr, tab[j], 0, (lptr_t)(st + (j * NLW + iw) * 1024));
+                return;
+            }
+            const int soff = (int)(((long)c * SB) % (bytes_per_wg - SB));
+#pragma unroll
+            for (int p = iw; p < SP; p += NLW)
+#pragma unroll
+                for (int q = 0; q < PPI; ++q)
+                    dma<WIDTH>(r, voff, soff + p * 1024 + q * 64 * WIDTH, (lptr_t)(st + p * 1024 + q * 64 * WIDTH));
+        };
+        for (int c = 0; c < NSTG - 1; ++c) issue(c);
+        for (int c = 0; c < nchunk; ++c) {
+            // stage c must have landed: with NSTG - 1 stages in flight wait for all but the NSTG - 2 youngest
+            if (NSTG == 2) bar_dma();
+            else { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(((SP + NLW - 1) / NLW) * PPI * (NSTG - 2)) : "memory"); }
+            if (c + NSTG - 1 < nchunk) issue(c + NSTG - 1);     // into the stage the MFMA waves left at this barrier
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // nothing in flight towards LDS when the workgroup ends
+    } else {
+        f32x16 acc[4] = {};
+        bf16x8 fr[6];
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) fr[i][j] = (__bf16)(float)(lane + i + j);
+        const char* rd0 = smem + lane * 16 + wave * 1024;
+        for (int c = 0; c < nchunk; ++c) {
+            bar_lds();                                           // stage c has landed, everyone left stage c - 1
+            const char* st = rd0 + (c % NSTG) * SB;
+            constexpr int G = NMF > 0 ? NMF / 6 : 1;             // 6 groups per chunk
+            if constexpr (RL) {
+                // the convolution kernel's own loop (conv3x3_ls_k, MT = 1, PT = 2): row-ordered groups (input row i, tap kx), one pixel
+                // fragment per group from the swizzled 18x34 halo image, weight fragments from the resident region behind the stages
+                // (chunk c & 3), 6-slot weight ring, reads 2 groups ahead, 2 accumulators
+                constexpr int IWT = 34, PT_ = 2, NGRP = 12, NG2 = 24, PD = 2, NRB = 3, NRA = 6;
+                const int r = lane & 31, h = lane >> 5;
+                const char* ls = smem + (c % NSTG) * SB;
+                const char* lsw = smem + NSTG * SB + (c & 3) * (9 * 32 * 64);
+                const int L0 = wave * PT_ * IWT + r;
+                const int pa = r * 64 + ((h ^ ((r >> 2) & 3)) * 16);
+                bf16x8 fa[NRA], fb[NRB];
+                auto read_b = [&](int GG) {
+                    const int ks = GG / NGRP, g = GG % NGRP;
+                    const int lp = L0 + (g / 3) * IWT + (g % 3);
+                    const int pb = lp * 64 + ((h ^ ((lp >> 2) & 3)) * 16);
+                    fb[GG % NRB] = *(const bf16x8*)(ls + (pb ^ (ks * 32)));
+                };
+                auto read_a = [&](int GG) {
+                    const int ks = GG / NGRP, g = GG % NGRP;
+                    if (g < 9) fa[g % NRA] = *(const bf16x8*)(lsw + (pa ^ (ks * 32)) + (g * 32) * 64);
+                };
+#pragma unroll
+                for (int GG = 0; GG < PD; ++GG) { read_a(GG); read_b(GG); }
+#pragma unroll
+                for (int GG = 0; GG < NG2; ++GG) {
+                    if (GG + PD < NG2) { read_a(GG + PD); read_b(GG + PD); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = GG % NGRP, i = g / 3, kx = g % 3;
+#pragma unroll
+                    for (int q = 0; q < PT_; ++q) {
+                        const int ky = i - q;
+                        if (ky < 0 || ky > 2) continue;
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(ky * 3 + kx) % NRA], fb[GG % NRB], acc[q], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (RD) {
+#pragma unroll
+                    for (int i = 0; i < NRD / 6; ++i) {
+                        // conflict-free: 64 lanes x 16 B contiguous
+                        const bf16x8 v = *(const bf16x8*)(st + ((g * (NRD / 6) + i) * 1024) % (SB - 8 * 1024));
+                        fr[i % 6] = v;
+                    }
+                }
+                if (MF) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 6], fr[(i + 1) % 6], acc[i & 3], 0, 0, 0);
+                } else if (RD) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(fr[i]));
+                }
+            }
+            if (EPI && (c & 3) == 3) {
+                // a unit's output: 16x32 pixels x 32 channels bf16 in one plane of the same blocked tensor; this wave's 2 rows, one pixel
+                // per lane pair, four 8-byte pieces per lane (the accumulator layout's store pattern)
+                const int ulo = (blockIdx.x & 7) * (gridDim.x >> 3) * (nchunk >> 2) + (blockIdx.x >> 3), ugw = gridDim.x >> 3;
+                const int ubase = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (nchunk >> 2);
+                const int u = ORD ? ulo + (c >> 2) * ugw : ubase + (c >> 2);
+                const int tx = u % 8, ty = (u / 8) % 16, img = (u / 128) & imask;
+                // EPI 1: the accumulator layout's store (8 B per lane, lanes r / r+32 fill a 16-byte piece, 4 instructions per row)
+                // EPI 2: 16 B per lane, lanes r / r+32 fill 32 contiguous bytes of pixel r (after a half-wave exchange), 2 per row
+                // EPI 3: 16 B per lane, 4 consecutive lanes = one pixel's 64 B (after a transposition), 2 instructions per row
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    char* row = dst + (((((long)img * 256 + ty * 16 + wave * 2 + q) * 256 + tx * 32) * 64) & dmask);
+                    if (EPI == 1) {
+                        char* o = row + (lane & 31) * 64 + (lane >> 5) * 8;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) { float2 v = {acc[q][4 * g], acc[q][4 * g + 1]}; *(float2*)(o + 16 * g) = v; }
+                    } else if (EPI == 2) {
+                        char* o = row + (lane & 31) * 64 + (lane >> 5) * 16;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) { float4 v = {acc[q][8 * g], acc[q][8 * g + 1], acc[q][8 * g + 2], acc[q][8 * g + 3]}; *(float4*)(o + 32 * g) = v; }
+                    } else {
+                        char* o = row + lane * 16;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) { float4 v = {acc[q][8 * g], acc[q][8 * g + 1], acc[q][8 * g + 2], acc[q][8 * g + 3]}; *(float4*)(o + 1024 * g) = v; }
+                    }
+                }
+            }
+        }
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i];
+        if (s == 123.456f) sink[0] = s;
+    }
+}
+
+template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH = 16, int PAT = 0, int EPI = 0, int ORD = 0, int RL = 0>
+static void run(const char* name, const char* buf, long total, float* sink, int nchunk, long span_per_wg, int imask = 15, long dmask = -1L) {
+    auto kern = k<DMA, RD, MF, NLW, NSTG, SP, NRD, NMF, WIDTH, PAT, EPI, ORD, RL>;
+    const size_t smem = (size_t)NSTG * SP * 1024 + (RL ? 72 * 1024 : 8 * 1024);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3((8 + NLW) * 64), smem, 0, buf, span_per_wg, nchunk, sink, (char*)buf + 4L * 16 * 256 * 256 * 64, imask, dmask);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double bytes = DMA ? 256.0 * nchunk * (PAT == 1 ? 18 * 34 * 64 : PAT == 2 ? 10 * 66 * 64 : SP * 1024) : 0, flops = MF ? 256.0 * 8 * nchunk * (NMF / 6 * 6) * 32768.0 : 0;
+    printf("%-46s %8.1f us  %5.2f TB/s  %5.2f PFLOP/s  (%.2f us per chunk)\n", name, best * 1e3, bytes / best / 1e9, flops / best / 1e12, best * 1e3 / nchunk);
+    if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(1); }
+}
+
+int main() {
+    const long total = 1L << 30;
+    char* buf; float* sink;
+    hipMalloc(&buf, total + 4096); hipLaunchKernelGGL(fill_k, dim3(4096), dim3(256), 0, 0, (unsigned short*)buf, total / 2); hipDeviceSynchronize(); hipMalloc(&sink, 64);
+    const int NC = 96;                      // chunks per workgroup: 96 x 40 KiB x 256 = 0.98 GB streamed from HBM
+    const long span = total / 256;
+    const long l2span = 1L << 19;           // 512 KiB per workgroup = 128 MiB in all: re-read, mostly out of the Infinity Cache
+    printf("-- stream from HBM (1 GiB), 40 KiB stages, 42 reads + 36 MFMAs per wave and chunk (the Cout = 32 loop)\n");
+    run<true,  false, false, 8, 2, 40, 42, 36>("DMA only", buf, total, sink, NC, span);
+    run<false, true,  true,  8, 2, 40, 42, 36>("reads + MFMA only", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36>("DMA + reads + MFMA", buf, total, sink, NC, span);
+    run<true,  false, true,  8, 2, 40, 42, 36>("DMA + MFMA (no reads)", buf, total, sink, NC, span);
+    run<true,  true,  false, 8, 2, 40, 42, 36>("DMA + reads (no MFMA)", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 24, 36>("all, 24 reads", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 12, 36>("all, 12 reads", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 3, 40, 42, 36>("all, 3 stages", buf, total, sink, NC, span);
+    run<true,  true,  true,  4, 2, 40, 42, 36>("all, 4 loader waves", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 42, 72>("all, 72 MFMAs (Cout = 64 ratio)", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 64, 42, 72>("all, 64 KiB stages, 72 MFMAs", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 4>("all, 4-byte DMA lanes", buf, total, sink, NC, span);
+    printf("-- the same from a 128 MiB window (Infinity Cache / L2)\n");
+    run<true,  false, false, 8, 2, 40, 42, 36>("DMA only", buf, total, sink, NC, l2span);
+    run<true,  true,  true,  8, 2, 40, 42, 36>("DMA + reads + MFMA", buf, total, sink, NC, l2span);
+    run<true,  true,  true,  8, 3, 40, 42, 36>("all, 3 stages", buf, total, sink, NC, l2span);
+    printf("-- the convolution's operand pattern: 18x34-pixel halo tiles in 4 channel planes of a [16,256,256] x 64 B tensor (268 MB)\n");
+    run<true,  false, false, 8, 2, 40, 42, 36, 16, 1>("halo pattern: DMA only", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1>("halo pattern: DMA + reads + MFMA", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 3, 40, 42, 36, 16, 1>("halo pattern: all, 3 stages", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1>("halo pattern, interleaved unit order", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 0>("halo pattern + output stores", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("halo pattern + stores, interleaved order", buf, total, sink, 32, span);
+    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("reads + MFMA + stores (no DMA)", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 3, 40, 42, 36, 16, 1, 1, 1>("halo + stores, interleaved, 3 stages", buf, total, sink, 32, span);
+    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1>("no DMA, stores 16 B: 32 B per pixel and instr.", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1>("all,    stores 16 B: 32 B per pixel and instr.", buf, total, sink, 32, span);
+    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("no DMA, stores 16 B: 1 KiB contiguous per instr.", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all,    stores 16 B: 1 KiB contiguous per instr.", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all, contiguous stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("all, 8-byte stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all, contiguous stores, 4 images (67 + 17 MB)", buf, total, sink, 32, span, 3);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("all, 8-byte stores, 4 images", buf, total, sink, 32, span, 3);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1>("all, no stores, 4 images", buf, total, sink, 32, span, 3);
+    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("kernel's MFMA loop alone", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("kernel's MFMA loop + DMA", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 1>("kernel's MFMA loop + DMA + 8-byte stores", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("kernel's MFMA loop + DMA + 16-byte stores", buf, total, sink, 32, span);
+    run<true,  false, false, 8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA only", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA + reads + MFMA", buf, total, sink, 32, span);
+    return 0;
+}

@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // Per-dtype constants.  A "piece" is 16 bytes; a K-chunk is 64 bytes of channels
 // per pixel (16 f32 or 32 bf16) so both dtypes share one LDS byte layout.

@@ -556,7 +556,13 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         }
         if constexpr (DIRECT) {
             if (direct_ok) {
-                if (!SG_DBG(p, 4)) conv_epilogue_direct32<T, PT, EM>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+#ifndef SG_DIRECT_X16
+#define SG_DIRECT_X16 1
+#endif
+                if (!SG_DBG(p, 4)) {
+                    if (SG_DIRECT_X16 && p.vec16) conv_epilogue_direct32<T, PT, EM, true>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+                    else conv_epilogue_direct32<T, PT, EM, false>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
+                }
                 continue;
             }
         }

@@ -408,7 +408,12 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 // scratch is a stage buffer); this one is ~150 VALU instructions per wave and needs no barrier, so a wave goes from its last
 // MFMA straight to its stores.  Bias comes from the LDS copy; the sign mask word of a pixel is read by both of its lanes, and
 // written by the h == 0 lane after a cross-half exchange.
-template <typename T, int PT, int EM>
+// X16 (ycoff % 8 == 0): the two lanes of a pixel (r, r + 32) first exchange halves with v_permlane32_swap so that each holds 8
+// CONSECUTIVE channels, and store 16 bytes: two instructions per row, each filling 32 contiguous bytes of every pixel record, instead
+// of four 8-byte ones.  The texture addresser's time goes with the store instructions (scripts/hip/ingest_test.hip, the kernel's
+// skeleton with all three streams running: 66.6 us with the 8-byte pattern, 62.8 with this one, 62.1 with fully transposed 1-KiB
+// stores, 48.8 without stores), and it is shared with the loaders' DMA.
+template <typename T, int PT, int EM, bool X16 = false>
 __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32x16 (&acc)[1][PT], const char* lds_bias,
                                                        int b, int oy0, int ox0, int lane) {
     typedef __attribute__((ext_vector_type(4))) T vec4T;
@@ -416,7 +421,7 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
     const int ox = ox0 + r;
     const bool xok = ox < p.OW;
     // the 32 channels of the slice lie inside one 64-byte chunk (ycoff % 32 == 0 for blocked tensors; interleaved: linear)
-    const long lch0 = (long)chan_off<T>(p.ycoff + 4 * h, p.yplane);
+    const long lch0 = (long)chan_off<T>(p.ycoff + (X16 ? 8 : 4) * h, p.yplane);
     // every row's sign word is requested before the first store: vmcnt counts stores too on gfx9, a load issued after a
     // row's stores could only be waited for together with them
     unsigned sgr[PT];
@@ -434,6 +439,7 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
         const unsigned sg = sgr[q];
         char* yp = (char*)p.y + pix * p.ypix;
         unsigned mine = 0u;
+        u32x2 pk[4];                                      // X16: the four channel groups as packed 16-bit pairs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             vec4T o;
@@ -446,8 +452,23 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
                 if (EM & 16) mine |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + i);
                 o[i] = from_f<T>(v);
             }
-            if (xok && !SG_DBG(p, 32)) *(vec4T*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
-            if (SG_DBG(p, 32)) asm volatile("" :: "v"(o));
+            if constexpr (X16) pk[g] = __builtin_bit_cast(u32x2, o);
+            else {
+                if (xok && !SG_DBG(p, 32)) *(vec4T*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
+                if (SG_DBG(p, 32)) asm volatile("" :: "v"(o));
+            }
+        }
+        if constexpr (X16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // lanes h = 0 hold channels 16j + {0..3} (pk[2j]) and 16j + 8 + {0..3} (pk[2j+1]); lanes h = 1 the +4 ones.  After the
+                // swap (upper half of x <-> lower half of y) a lane holds x', y' = channels 16j + 8h + {0..3}, + {4..7}.
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+                const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
+                if (xok && !SG_DBG(p, 32)) *(u32x4*)(yp + lch0 + 32 * j) = o16;
+                if (SG_DBG(p, 32)) asm volatile("" :: "v"(o16));
+            }
         }
         if (EM & 16) {
             const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
