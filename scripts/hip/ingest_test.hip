@@ -11,6 +11,7 @@
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // random bf16 values in (-0.5, 0.5): the matrix pipe's power (hence the clock) depends on the operand bits
 __global__ void fill_k(unsigned short* p, long n) {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
         __builtin_amdgcn_s_waitcnt(0x0f70);                      // nothing in flight towards LDS when the workgroup ends
     } else {
         f32x16 acc[4] = {};
+        f32x4 acc4[8] = {};
         bf16x8 fr[6];
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) fr[i][j] = (__bf16)(float)(lane + i + j);
         const char* rd0 = smem + lane * 16 + wave * 1024;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
             bar_lds();                                           // stage c has landed, everyone left stage c - 1
             const char* st = rd0 + (c % NSTG) * SB;
             constexpr int G = NMF > 0 ? NMF / 6 : 1;             // 6 groups per chunk
-            if constexpr (RL) {
+            if constexpr (RL == 1) {
                 // the convolution kernel's own loop (conv3x3_ls_k, MT = 1, PT = 2): row-ordered groups (input row i, tap kx), one pixel
                 // fragment per group from the swizzled 18x34 halo image, weight fragments from the resident region behind the stages
                 // (chunk c & 3), 6-slot weight ring, reads 2 groups ahead, 2 accumulators
@@ -146,7 +148,10 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                         fr[i % 6] = v;
                     }
                 }
-                if (MF) {
+                if (MF && RL == 2) {          // the same FLOPs as 16x16x32 MFMAs (two per 32x32x16)
+#pragma unroll
+                    for (int i = 0; i < 2 * G; ++i) acc4[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % 6], fr[(i + 1) % 6], acc4[i & 7], 0, 0, 0);
+                } else if (MF) {
 #pragma unroll
                     for (int i = 0; i < G; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 6], fr[(i + 1) % 6], acc[i & 3], 0, 0, 0);
                 } else if (RD) {
@@ -171,6 +176,10 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                         char* o = row + (lane & 31) * 64 + (lane >> 5) * 8;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) { float2 v = {acc[q][4 * g], acc[q][4 * g + 1]}; *(float2*)(o + 16 * g) = v; }
+                    } else if (EPI == 4) {
+                        char* o = row + (lane & 31) * 64 + (lane >> 5) * 16;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) { f32x4 v = {acc[q][8 * g], acc[q][8 * g + 1], acc[q][8 * g + 2], acc[q][8 * g + 3]}; __builtin_nontemporal_store(v, (f32x4*)(o + 32 * g)); }
                     } else if (EPI == 2) {
                         char* o = row + (lane & 31) * 64 + (lane >> 5) * 16;
 #pragma unroll
@@ -185,6 +194,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
         }
         float s = 0.f;
         for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i];
+        for (int i = 0; i < 8; ++i) s += acc4[i][0] + acc4[i][3];
         if (s == 123.456f) sink[0] = s;
     }
 }
@@ -192,7 +202,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
 template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH = 16, int PAT = 0, int EPI = 0, int ORD = 0, int RL = 0>
 static void run(const char* name, const char* buf, long total, float* sink, int nchunk, long span_per_wg, int imask = 15, long dmask = -1L) {
     auto kern = k<DMA, RD, MF, NLW, NSTG, SP, NRD, NMF, WIDTH, PAT, EPI, ORD, RL>;
-    const size_t smem = (size_t)NSTG * SP * 1024 + (RL ? 72 * 1024 : 8 * 1024);
+    const size_t smem = (size_t)NSTG * SP * 1024 + (RL == 1 ? 72 * 1024 : 8 * 1024);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
@@ -254,6 +264,17 @@ int main() {
     run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("kernel's MFMA loop + DMA", buf, total, sink, 32, span);
     run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 1>("kernel's MFMA loop + DMA + 8-byte stores", buf, total, sink, 32, span);
     run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("kernel's MFMA loop + DMA + 16-byte stores", buf, total, sink, 32, span);
+    printf("-- repeats (thermal drift) and variants\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 0>("32x32x16: DMA + reads + MFMA", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 2>("16x16x32: DMA + reads + MFMA", buf, total, sink, 32, span);
+        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 0>("32x32x16: reads + MFMA", buf, total, sink, 32, span);
+        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 2>("16x16x32: reads + MFMA", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 0>("all, 8-byte stores", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 0>("all, 16-byte pair stores", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 4, 1, 0>("all, 16-byte pair stores, nontemporal", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1, 0>("all, 1-KiB contiguous stores", buf, total, sink, 32, span);
+    }
     run<true,  false, false, 8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA only", buf, total, sink, 32, span);
     run<true,  true,  true,  8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA + reads + MFMA", buf, total, sink, 32, span);
     return 0;

@@ -466,7 +466,16 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
                 const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
-                if (xok && !SG_DBG(p, 32)) *(u32x4*)(yp + lch0 + 32 * j) = o16;
+// Nontemporal stores: in the skeleton (scripts/hip/ingest_test.hip) they take the stores' cost away (69 -> 62.5 us); in this kernel
+// they are SLOWER (back to back 64->32 49 -> 52 us, 96->32 61 -> 66; training step 137.3 -> 140.1 ms, same-box A/B): the block's next
+// convolution reads these 32 channels straight back, and the default policy keeps them in the Infinity Cache.  Off.
+#ifndef SG_DIRECT_NT
+#define SG_DIRECT_NT 0
+#endif
+                if (xok && !SG_DBG(p, 32)) {
+                    if (SG_DIRECT_NT) __builtin_nontemporal_store(o16, (u32x4*)(yp + lch0 + 32 * j));
+                    else *(u32x4*)(yp + lch0 + 32 * j) = o16;
+                }
                 if (SG_DBG(p, 32)) asm volatile("" :: "v"(o16));
             }
         }
