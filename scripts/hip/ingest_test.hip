@@ -1,10 +1,15 @@
-// Micro-benchmark of the loader-specialised convolution's skeleton on every CU: does an LDS-DMA stage land while 8 MFMA waves
-// read fragments from the other stage and feed the matrix pipe?  (the Cout = 32 convolutions take
-// 68 us where the operand stream alone takes 46 and the MFMA loop alone 48.)
-//   one workgroup per CU = 8 MFMA waves + NLW loader waves, NSTG stage buffers of SP KiB in LDS, one barrier per chunk;
-//   loaders: SP 1-KiB pieces per chunk (buffer_load_dwordx4 ... lds, per-lane offsets fixed, scalar offset advances through SRC);
-//   MFMA waves: per chunk NRD ds_read_b128 from the stage that has landed + NMF 32x32x16 bf16 MFMAs fed by them.
-// Template switches remove one stream at a time (no run-time branches in the loops).  Output: us per launch, TB/s, PFLOP/s.
+// Skeleton of the loader-specialised 3x3 convolution (csrc/conv3x3_dma.hip, Cout = 32 form) on every CU: which of its streams
+// overlap, and what does each cost?  
+//   one workgroup per CU = 8 MFMA waves + NLW loader waves, NSTG stage buffers in LDS, one barrier per K chunk;
+//   loaders: a stage per chunk by `buffer_load_dwordx4 ... lds` -- either flat 1-KiB pieces of a stream, or (PAT) the kernel's
+//            18x34-pixel halo tile of one 64-byte channel plane of a [16, 256, 256] blocked tensor, per-lane offsets fixed;
+//   MFMA waves: per chunk either generic groups of ds_read_b128 + 32x32x16 bf16 MFMAs, or (RL = 1) the kernel's own row-ordered
+//            loop (swizzled pixel fragments, resident weight fragments, 42 reads + 36 MFMAs per wave and chunk, 2 accumulators);
+//   EPI: a unit's output stores after its 4th chunk (8 B per lane as the accumulator layout gives them / 16 B lane pairs /
+//            1 KiB contiguous per instruction / nontemporal).
+// Every stream is a template switch (no run-time branches in the loops).  `ingest_test.bin const|random [all]`: the operand
+// bits matter -- the part is power-limited and the matrix pipe's clock follows their toggling.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 ingest_test.hip -o ingest_test.bin ; output of a run: profiles/r02_conv_skeleton.txt
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -218,64 +223,43 @@ static void run(const char* name, const char* buf, long total, float* sink, int 
     if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(1); }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // usage: ingest_test.bin [const|random] [all]   -- operand bits; "all" adds the exploratory variants
+    const bool constant = argc > 1 && argv[1][0] == 'c', all = argc > 2;
     const long total = 1L << 30;
     char* buf; float* sink;
-    hipMalloc(&buf, total + 4096); hipLaunchKernelGGL(fill_k, dim3(4096), dim3(256), 0, 0, (unsigned short*)buf, total / 2); hipDeviceSynchronize(); hipMalloc(&sink, 64);
-    const int NC = 96;                      // chunks per workgroup: 96 x 40 KiB x 256 = 0.98 GB streamed from HBM
+    hipMalloc(&buf, total + 4096);
+    if (constant) hipMemset(buf, 1, total);
+    else hipLaunchKernelGGL(fill_k, dim3(4096), dim3(256), 0, 0, (unsigned short*)buf, total / 2);
+    hipDeviceSynchronize(); hipMalloc(&sink, 64);
     const long span = total / 256;
-    const long l2span = 1L << 19;           // 512 KiB per workgroup = 128 MiB in all: re-read, mostly out of the Infinity Cache
-    printf("-- stream from HBM (1 GiB), 40 KiB stages, 42 reads + 36 MFMAs per wave and chunk (the Cout = 32 loop)\n");
+    printf("operand bits: %s.  Shape of the 128 -> 32 dense-block convolution at the bench size: 2048 units x 4 chunks, 268 MB in, 67 MB out, 77 GFLOP\n",
+           constant ? "constant (every byte 0x01)" : "random bf16 in (-0.5, 0.5)");
+    for (int rep = 0; rep < 2; ++rep) {
+        run<true,  false, false, 8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("DMA only (halo stages)", buf, total, sink, 32, span);
+        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("MFMA loop only (kernel's reads + MFMAs)", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("DMA + MFMA loop", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 1>("DMA + MFMA loop + stores, 8 B per lane", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("DMA + MFMA loop + stores, 16 B lane pairs", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 4, 1, 1>("  the same, nontemporal", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1, 1>("DMA + MFMA loop + stores, 1 KiB contiguous", buf, total, sink, 32, span);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("16 B stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
+        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("16 B stores, 4 images (cache-resident)", buf, total, sink, 32, span, 3);
+        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("MFMA loop + 16 B stores (no DMA)", buf, total, sink, 32, span);
+    }
+    if (!all) return 0;
+    const int NC = 96;
+    printf("-- flat 1-KiB pieces streamed from 1 GiB, generic read/MFMA groups\n");
     run<true,  false, false, 8, 2, 40, 42, 36>("DMA only", buf, total, sink, NC, span);
     run<false, true,  true,  8, 2, 40, 42, 36>("reads + MFMA only", buf, total, sink, NC, span);
     run<true,  true,  true,  8, 2, 40, 42, 36>("DMA + reads + MFMA", buf, total, sink, NC, span);
     run<true,  false, true,  8, 2, 40, 42, 36>("DMA + MFMA (no reads)", buf, total, sink, NC, span);
     run<true,  true,  false, 8, 2, 40, 42, 36>("DMA + reads (no MFMA)", buf, total, sink, NC, span);
-    run<true,  true,  true,  8, 2, 40, 24, 36>("all, 24 reads", buf, total, sink, NC, span);
-    run<true,  true,  true,  8, 2, 40, 12, 36>("all, 12 reads", buf, total, sink, NC, span);
     run<true,  true,  true,  8, 3, 40, 42, 36>("all, 3 stages", buf, total, sink, NC, span);
     run<true,  true,  true,  4, 2, 40, 42, 36>("all, 4 loader waves", buf, total, sink, NC, span);
-    run<true,  true,  true,  8, 2, 40, 42, 72>("all, 72 MFMAs (Cout = 64 ratio)", buf, total, sink, NC, span);
-    run<true,  true,  true,  8, 2, 64, 42, 72>("all, 64 KiB stages, 72 MFMAs", buf, total, sink, NC, span);
+    run<true,  true,  true,  8, 2, 40, 42, 72>("all, 72 MFMAs per chunk (Cout = 64 ratio)", buf, total, sink, NC, span);
     run<true,  true,  true,  8, 2, 40, 42, 36, 4>("all, 4-byte DMA lanes", buf, total, sink, NC, span);
-    printf("-- the same from a 128 MiB window (Infinity Cache / L2)\n");
-    run<true,  false, false, 8, 2, 40, 42, 36>("DMA only", buf, total, sink, NC, l2span);
-    run<true,  true,  true,  8, 2, 40, 42, 36>("DMA + reads + MFMA", buf, total, sink, NC, l2span);
-    run<true,  true,  true,  8, 3, 40, 42, 36>("all, 3 stages", buf, total, sink, NC, l2span);
-    printf("-- the convolution's operand pattern: 18x34-pixel halo tiles in 4 channel planes of a [16,256,256] x 64 B tensor (268 MB)\n");
-    run<true,  false, false, 8, 2, 40, 42, 36, 16, 1>("halo pattern: DMA only", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1>("halo pattern: DMA + reads + MFMA", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 3, 40, 42, 36, 16, 1>("halo pattern: all, 3 stages", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1>("halo pattern, interleaved unit order", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 0>("halo pattern + output stores", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("halo pattern + stores, interleaved order", buf, total, sink, 32, span);
-    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("reads + MFMA + stores (no DMA)", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 3, 40, 42, 36, 16, 1, 1, 1>("halo + stores, interleaved, 3 stages", buf, total, sink, 32, span);
-    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1>("no DMA, stores 16 B: 32 B per pixel and instr.", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1>("all,    stores 16 B: 32 B per pixel and instr.", buf, total, sink, 32, span);
-    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("no DMA, stores 16 B: 1 KiB contiguous per instr.", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all,    stores 16 B: 1 KiB contiguous per instr.", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all, contiguous stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("all, 8-byte stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1>("all, contiguous stores, 4 images (67 + 17 MB)", buf, total, sink, 32, span, 3);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1>("all, 8-byte stores, 4 images", buf, total, sink, 32, span, 3);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1>("all, no stores, 4 images", buf, total, sink, 32, span, 3);
-    run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("kernel's MFMA loop alone", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("kernel's MFMA loop + DMA", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 1>("kernel's MFMA loop + DMA + 8-byte stores", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("kernel's MFMA loop + DMA + 16-byte stores", buf, total, sink, 32, span);
-    printf("-- repeats (thermal drift) and variants\n");
-    for (int rep = 0; rep < 2; ++rep) {
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 0>("32x32x16: DMA + reads + MFMA", buf, total, sink, 32, span);
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 2>("16x16x32: DMA + reads + MFMA", buf, total, sink, 32, span);
-        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 0>("32x32x16: reads + MFMA", buf, total, sink, 32, span);
-        run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 2>("16x16x32: reads + MFMA", buf, total, sink, 32, span);
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 1, 1, 0>("all, 8-byte stores", buf, total, sink, 32, span);
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 0>("all, 16-byte pair stores", buf, total, sink, 32, span);
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 4, 1, 0>("all, 16-byte pair stores, nontemporal", buf, total, sink, 32, span);
-        run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 3, 1, 0>("all, 1-KiB contiguous stores", buf, total, sink, 32, span);
-    }
-    run<true,  false, false, 8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA only", buf, total, sink, 32, span);
-    run<true,  true,  true,  8, 2, 42, 42, 36, 16, 2>("8x64 tiles: DMA + reads + MFMA", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 2>("halo stages, 16x16x32 MFMAs", buf, total, sink, 32, span);
+    run<true,  true,  true,  8, 2, 42, 42, 36, 16, 2>("8x64-pixel tiles: DMA + reads + MFMA", buf, total, sink, 32, span);
     return 0;
 }
