@@ -7,8 +7,15 @@ from srcgan_amd import ops
 B, H, W, nf, gc = int(os.environ.get("MB_B", "16")), 256, 256, 64, 32
 Cc = nf + 4 * gc
 torch.manual_seed(0)
-A = (torch.rand(B, H, W, Cc, device="cuda") - 0.5).to(torch.bfloat16)
-Gd = (torch.rand(B, H, W, Cc, device="cuda") - 0.5).to(torch.bfloat16)
+# MB_DATA: random (default) | const (every element 0.25) | sparse (half of the elements zero, like a ReLU's output) -- the matrix
+# pipe's power, hence its clock, follows the toggling of the operand bits
+mode = os.environ.get("MB_DATA", "random")
+def data():
+    t = torch.rand(B, H, W, Cc, device="cuda") - 0.5
+    if mode == "const": t = torch.full_like(t, 0.25)
+    if mode == "sparse": t = torch.relu(t)
+    return t.to(torch.bfloat16)
+A, Gd = data(), data()
 segs, fl = [], 0.0
 for m in (5, 4, 3, 2, 1):
     g0 = 0 if m == 5 else nf + (4 - m) * gc
@@ -28,4 +35,4 @@ e0.record()
 for _ in range(10): f()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
-print(f"wgrad_dense block: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s (useful)")
+print(f"wgrad_dense block ({mode} operands): {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s (useful)")
