@@ -57,7 +57,21 @@ __global__ __launch_bounds__((NCW + (BIASW ? 1 : 0)) * 64) void conv_wgrad_k(con
     char* lds_x = smem + MT * TH * TW * PB;          // [IHT*IWT][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int cit = blockIdx.x, ct = blockIdx.y, split = blockIdx.z;
+    // Workgroup -> (input-channel tile, output-channel tile, pixel range).  The citiles x ctiles workgroups of one pixel range read
+    // the same dy / x tiles (each its own 64-byte channel slice of every pixel record): they get consecutive slots of ONE XCD, so
+    // the lines one of them pulls in serve the others from that L2.  (With grid = (citiles, ctiles, nsplit) neighbours in the
+    // channel dimensions landed on different XCDs -- round-robin by linear id -- and every L2 fetched the lines again.)
+#ifndef SG_WG_XCD
+#define SG_WG_XCD 1
+#endif
+    int cit, ct, split;
+    if (SG_WG_XCD) {
+        const int L = blockIdx.x, pairs = p.citiles * p.ctiles;
+        const int j = L >> 3, pr = j % pairs;
+        split = (j / pairs) * 8 + (L & 7);
+        if (split >= p.nsplit) return;
+        cit = pr % p.citiles; ct = pr / p.citiles;
+    } else { cit = blockIdx.x; ct = blockIdx.y; split = blockIdx.z; }
     const int part = tid % PPP;
     const bool bias_wave = BIASW && wave == NCW;
     const bool do_bias = bias_wave && cit == 0 && p.want_bias;
@@ -316,6 +330,7 @@ static int launch_wgrad(WgradP p, hipStream_t st) {
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
     dim3 grid((unsigned)p.citiles, (unsigned)p.ctiles, (unsigned)p.nsplit);
+    if (SG_WG_XCD) grid = dim3((unsigned)(p.citiles * p.ctiles * ((p.nsplit + 7) / 8) * 8), 1, 1);
     char cls[96];
     snprintf(cls, sizeof(cls), "conv_wgrad<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), KH, KW, S, MT);
     const double px = (double)p.B * p.OH * p.OW;
