@@ -327,8 +327,9 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
         // into a 256-byte dummy region touches every 64-byte line of the chunk after the one being issued: its HBM latency
         // overlaps the current landings, and the real DMA of that chunk then reads L2.
         // MEASURED (round 2, scripts/microbench_conv.py, blocked layout): with the prefetch 64->32 50.8 -> 53.8 us, 128->32 83.5 -> 88.4,
-        // 160->32 111 -> 118, 192->64 239 -> 246: 3-7 % SLOWER.  More bytes in flight towards HBM do not help: the landing rate
-        // is set on the CU side of L2 (LDS-DMA ingest beside the MFMA waves' LDS traffic), not by HBM latency.  Off by default.
+        // 160->32 111 -> 118, 192->64 239 -> 246: 3-7 % SLOWER.  More bytes in flight towards HBM do not help: the kernel's skeleton
+        // (scripts/hip/ingest_test.hip) overlaps DMA, fragment reads and MFMAs fully with two stages -- what costs is the part's
+        // power limit and the output stores, not memory latency.  Off by default.
 #ifndef SG_PF
 #define SG_PF 0
 #endif
