@@ -36,7 +36,7 @@ __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n
 __device__ __forceinline__ void bar_dma() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // DMA: loaders stream; RD: fragment reads; MF: MFMAs; NLW loader waves; NSTG stages; SP KiB per stage; NRD reads, NMF MFMAs per chunk
-template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH, int PAT, int EPI, int ORD, int RL>
+template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH, int PAT, int EPI, int ORD, int RL, int EPV = 0>
 __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_per_wg, int nchunk, float* sink, char* dst, int imask, long dmask) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -102,6 +102,27 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
         bf16x8 fr[6];
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) fr[i][j] = (__bf16)(float)(lane + i + j);
         const char* rd0 = smem + lane * 16 + wave * 1024;
+        // EPI 5 / 6 (round 3): the finished unit's accumulators are copied to a second set and its four 16-byte stores (with EPV
+        // dummy conversion instructions each, standing in for bias / LeakyReLU / packing) are issued INSIDE the next unit's MFMA
+        // groups -- EPI 5: all four in the next unit's first chunk (groups 3, 9, 15, 21); EPI 6: one per chunk of the next unit.
+        f32x16 accp[2] = {};
+        auto store_piece = [&](int uc, int k) __attribute__((always_inline)) {      // piece k = (row q, half g) of the unit that ended with chunk uc
+            const int ulo = (blockIdx.x & 7) * (gridDim.x >> 3) * (nchunk >> 2) + (blockIdx.x >> 3), ugw = gridDim.x >> 3;
+            const int ubase = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (nchunk >> 2);
+            const int u = ORD ? ulo + (uc >> 2) * ugw : ubase + (uc >> 2);
+            const int tx = u % 8, ty = (u / 8) % 16, img = (u / 128) & imask;
+            const int q = k >> 1, g = k & 1;
+            char* row = dst + (((((long)img * 256 + ty * 16 + wave * 2 + q) * 256 + tx * 32) * 64) & dmask);
+            char* o = row + (lane & 31) * 64 + (lane >> 5) * 16;
+            float4 v = {accp[q][8 * g], accp[q][8 * g + 1], accp[q][8 * g + 2], accp[q][8 * g + 3]};
+            if (EPV) {          // stand-in for the production epilogue's arithmetic on the 8 values a 16-byte store carries
+                float w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { float t = accp[q][8 * g + i] + 0.25f; t = t > 0.f ? t : t * 0.2f; w[i] = t; }
+                v.x = w[0] + w[4]; v.y = w[1] + w[5]; v.z = w[2] + w[6]; v.w = w[3] + w[7];
+            }
+            *(float4*)(o + 32 * g) = v;
+        };
         for (int c = 0; c < nchunk; ++c) {
             bar_lds();                                           // stage c has landed, everyone left stage c - 1
             const char* st = rd0 + (c % NSTG) * SB;
@@ -140,6 +161,8 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                         if (ky < 0 || ky > 2) continue;
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(ky * 3 + kx) % NRA], fb[GG % NRB], acc[q], 0, 0, 0);
                     }
+                    if constexpr (EPI == 5) { if (GG % 6 == 3 && c >= 4 && (c & 3) == 0) store_piece(c - 1, GG / 6); }
+                    if constexpr (EPI == 6) { if (GG == 9 && c >= 4) store_piece((c & ~3) - 1, c & 3); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else
@@ -164,7 +187,8 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                     for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(fr[i]));
                 }
             }
-            if (EPI && (c & 3) == 3) {
+            if ((EPI == 5 || EPI == 6) && (c & 3) == 3) { accp[0] = acc[0]; accp[1] = acc[1]; }
+            else if (EPI && (c & 3) == 3) {
                 // a unit's output: 16x32 pixels x 32 channels bf16 in one plane of the same blocked tensor; this wave's 2 rows, one pixel
                 // per lane pair, four 8-byte pieces per lane (the accumulator layout's store pattern)
                 const int ulo = (blockIdx.x & 7) * (gridDim.x >> 3) * (nchunk >> 2) + (blockIdx.x >> 3), ugw = gridDim.x >> 3;
@@ -188,7 +212,16 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                     } else if (EPI == 2) {
                         char* o = row + (lane & 31) * 64 + (lane >> 5) * 16;
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) { float4 v = {acc[q][8 * g], acc[q][8 * g + 1], acc[q][8 * g + 2], acc[q][8 * g + 3]}; *(float4*)(o + 32 * g) = v; }
+                        for (int g = 0; g < 2; ++g) {
+                            float4 v = {acc[q][8 * g], acc[q][8 * g + 1], acc[q][8 * g + 2], acc[q][8 * g + 3]};
+                            if (EPV) {
+                                float w[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) { float t = acc[q][8 * g + i] + 0.25f; t = t > 0.f ? t : t * 0.2f; w[i] = t; }
+                                v.x = w[0] + w[4]; v.y = w[1] + w[5]; v.z = w[2] + w[6]; v.w = w[3] + w[7];
+                            }
+                            *(float4*)(o + 32 * g) = v;
+                        }
                     } else {
                         char* o = row + lane * 16;
 #pragma unroll
@@ -197,6 +230,7 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
                 }
             }
         }
+        if (EPI == 5 || EPI == 6) for (int k = 0; k < 4; ++k) store_piece(nchunk - 1, k);
         float s = 0.f;
         for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i];
         for (int i = 0; i < 8; ++i) s += acc4[i][0] + acc4[i][3];
@@ -204,9 +238,9 @@ __global__ __launch_bounds__((8 + NLW) * 64) void k(const char* src, long bytes_
     }
 }
 
-template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH = 16, int PAT = 0, int EPI = 0, int ORD = 0, int RL = 0>
+template <bool DMA, bool RD, bool MF, int NLW, int NSTG, int SP, int NRD, int NMF, int WIDTH = 16, int PAT = 0, int EPI = 0, int ORD = 0, int RL = 0, int EPV = 0>
 static void run(const char* name, const char* buf, long total, float* sink, int nchunk, long span_per_wg, int imask = 15, long dmask = -1L) {
-    auto kern = k<DMA, RD, MF, NLW, NSTG, SP, NRD, NMF, WIDTH, PAT, EPI, ORD, RL>;
+    auto kern = k<DMA, RD, MF, NLW, NSTG, SP, NRD, NMF, WIDTH, PAT, EPI, ORD, RL, EPV>;
     const size_t smem = (size_t)NSTG * SP * 1024 + (RL == 1 ? 72 * 1024 : 8 * 1024);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -225,7 +259,7 @@ static void run(const char* name, const char* buf, long total, float* sink, int 
 
 int main(int argc, char** argv) {
     // usage: ingest_test.bin [const|random] [all]   -- operand bits; "all" adds the exploratory variants
-    const bool constant = argc > 1 && argv[1][0] == 'c', all = argc > 2;
+    const bool constant = argc > 1 && argv[1][0] == 'c', all = argc > 2 && argv[2][0] == 'a';
     const long total = 1L << 30;
     char* buf; float* sink;
     hipMalloc(&buf, total + 4096);
@@ -246,6 +280,23 @@ int main(int argc, char** argv) {
         run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("16 B stores into a 4 MiB window", buf, total, sink, 32, span, 15, (4L << 20) - 1);
         run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("16 B stores, 4 images (cache-resident)", buf, total, sink, 32, span, 3);
         run<false, true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1>("MFMA loop + 16 B stores (no DMA)", buf, total, sink, 32, span);
+    }
+    if (argc > 2 && argv[2][0] == 'e') {
+        // round 3: the unit's stores issued inside the NEXT unit's MFMA groups (second accumulator set), interleaved A/B, 3 rounds
+        for (int rep = 0; rep < 3; ++rep) {
+            run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 0, 1, 1>("8 loaders: DMA + MFMA loop (no stores)", buf, total, sink, 32, span);
+            run<true,  true,  true,  8, 2, 40, 42, 36, 16, 1, 2, 1, 1, 1>("8 loaders: stores + arithmetic at unit end", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 0, 1, 1>("4 loaders: DMA + MFMA loop (no stores)", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 2, 1, 1>("4 loaders: stores at unit end", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 2, 1, 1, 1>("4 loaders: stores + arithmetic at unit end", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 5, 1, 1>("4 loaders: stores deferred into next chunk 0", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 5, 1, 1, 1>("4 loaders: stores + arithmetic deferred, chunk 0", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 6, 1, 1>("4 loaders: stores deferred, one per chunk", buf, total, sink, 32, span);
+            run<true,  true,  true,  4, 2, 40, 42, 36, 16, 1, 6, 1, 1, 1>("4 loaders: stores + arithmetic deferred, 1/chunk", buf, total, sink, 32, span);
+            run<false, true,  true,  4, 2, 40, 42, 36, 16, 1, 6, 1, 1, 1>("  the same without DMA", buf, total, sink, 32, span);
+            run<false, true,  true,  4, 2, 40, 42, 36, 16, 1, 2, 1, 1, 1>("  unit-end stores + arithmetic without DMA", buf, total, sink, 32, span);
+        }
+        return 0;
     }
     if (!all) return 0;
     const int NC = 96;

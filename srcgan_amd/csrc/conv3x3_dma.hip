@@ -226,7 +226,11 @@ __device__ __forceinline__ void dma_buf16(const void* base, int nrec, int voff, 
 // holds only the halo tile.  For Cout <= 32 the stage traffic, not the matrix pipe, bounds the chunk period (traced:
 // 2.6 us per chunk against 1.2 us of MFMA), and the weights are 18 of the 57 KiB a stage moves.  Needs ctiles == 1 and
 // nchunk * 18 KiB + two halo stages within 160 KiB (Cin <= 128 in bf16).
-template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG = 2, int PT = 2>
+// DIR: the epilogue form, chosen on the HOST (launch_ls): 0 = generic per-element form (any alignment), 1 = direct from the accumulator
+// layout with 8-byte stores, 2 = direct with 16-byte lane-pair stores, 3 = LDS-transposed rows (every operand 16-byte accessible: p.vec16).  As a run-time branch inside one kernel both epilogues shared a register allocation
+// and the compiler's pending-load state of the unused one (exec-masked mask loads) put `s_waitcnt vmcnt(0)` at the head of every chunk
+// loop of the gradient-slice class: on gfx9 vmcnt counts stores, so each unit's first chunk waited for the previous unit's output stores.
+template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG = 2, int PT = 2, int DIR = 0>
 __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP p) {
     using D = DT<T>;
     constexpr int NWV = 16 / PT;      // MFMA waves: PT output rows each, 16 rows per unit
@@ -248,12 +252,8 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
     const int bias_off = NSTG * SBYTES + wres_bytes;
     constexpr int ERS = COT * 4 + 16;
     // dense-block convolutions: epilogue straight from the accumulator layout (conv_epilogue_direct32), no scratch, no barrier
-#ifdef SG_NO_DIRECT_EPI
-    constexpr bool DIRECT = false;
-#else
-    constexpr bool DIRECT = MT == 1 && sizeof(T) == 2 && (EM == 0 || EM == 8 || EM == 16);
-#endif
-    const bool direct_ok = p.Cout == 32 && p.os == 1 && p.oa == 0 && p.ob == 0 && p.YH == p.OH && p.YW == p.OW && (p.yplane == 64 ? p.ycoff % 4 == 0 : p.ycoff % 32 == 0);
+    constexpr bool DIRECT = DIR == 1 || DIR == 2;
+    static_assert(!DIRECT || (MT == 1 && sizeof(T) == 2 && (EM == 0 || EM == 8 || EM == 16)), "direct epilogue: 16-bit dense-block convolutions");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
                 }
 #endif
             }
-            if (p.vec16 && !(DIRECT && direct_ok)) sg_barrier_raw();       // matches the MFMA waves' pre-epilogue barrier; the next stage keeps flying
+            if constexpr (DIR == 3) sg_barrier_raw();       // matches the MFMA waves' pre-epilogue barrier; the next stage keeps flying
         }
         return;
     }
@@ -489,6 +489,11 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             for (int q = 0; q < PT; ++q)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+#ifndef SG_SIGN_EARLY
+#define SG_SIGN_EARLY 1
+#endif
+        [[maybe_unused]] unsigned sgpre[PT];
+        if constexpr (DIRECT && (EM & 8) != 0 && SG_SIGN_EARLY) conv_direct32_sign_request<PT>(p, sgpre, cb, coy0 + wave * PT, cox0, lane);
         for (int c = 0; c < p.nchunk; ++c, stage = (stage + 1 == NSTG ? 0 : stage + 1)) {
 #ifdef SG_TRACE
             const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
@@ -556,18 +561,11 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             }
         }
         if constexpr (DIRECT) {
-            if (direct_ok) {
-#ifndef SG_DIRECT_X16
-#define SG_DIRECT_X16 1
-#endif
-                if (!SG_DBG(p, 4)) {
-                    if (SG_DIRECT_X16 && p.vec16) conv_epilogue_direct32<T, PT, EM, true>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
-                    else conv_epilogue_direct32<T, PT, EM, false>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane);
-                }
-                continue;
+            if (!SG_DBG(p, 4)) {
+                constexpr bool PRE = (EM & 8) != 0 && SG_SIGN_EARLY;
+                conv_epilogue_direct32<T, PT, EM, DIR == 2, PRE>(p, acc, smem + bias_off, cb, coy0 + wave * PT, cox0, lane, sgpre);
             }
-        }
-        if (p.vec16) {
+        } else if constexpr (DIR == 3) {
 #ifdef SG_TRACE
             const unsigned long long t_pre = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -589,12 +587,35 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
     }
 }
 
+template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG, int PT, int DIR>
+static int launch_ls_dir(const ConvP& p, int ctiles, hipStream_t st);
+
+#ifndef SG_DIRECT_X16
+#define SG_DIRECT_X16 1
+#endif
+// Dense-block convolutions (16-bit, 32 output channels, unscaled unit-stride output, no residual operands) take the direct epilogue.
 template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG = 2, int PT = 2>
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
+#ifndef SG_NO_DIRECT_EPI
+    if constexpr (MT == 1 && sizeof(T) == 2 && (EM == 0 || EM == 8 || EM == 16)) {
+        const bool direct_ok = p.Cout == 32 && p.os == 1 && p.oa == 0 && p.ob == 0 && p.YH == p.OH && p.YW == p.OW && (p.yplane == 64 ? p.ycoff % 4 == 0 : p.ycoff % 32 == 0);
+        if (direct_ok) return (SG_DIRECT_X16 && p.vec16) ? launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 2>(p, ctiles, st) : launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 1>(p, ctiles, st);
+    }
+#endif
+    if (p.vec16) return launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 3>(p, ctiles, st);
+    if constexpr (EM == 8 || EM == 16) {
+        SG_REQUIRE(false, "conv3x3: sign masks need 16-byte accessible operands");
+        return 1;
+    } else
+        return launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 0>(p, ctiles, st);
+}
+
+template <typename T, int MT, int NLW, bool WRES, int EM, int NSTG, int PT, int DIR>
+static int launch_ls_dir(const ConvP& p, int ctiles, hipStream_t st) {
     constexpr int HB = (((18 * 34 * 64 + 1023) / 1024 + NLW - 1) / NLW) * NLW * 1024, WB = WRES ? 0 : ((9 * 32 * MT * 64 / 1024 + NLW - 1) / NLW) * NLW * 1024;
     constexpr size_t SMEM = WRES ? 160 * 1024 : 2 * ((size_t)HB + (size_t)WB) + 4096 + 256;  // + bias copy (<= 1024 output channels) + prefetch dummy
     static_assert(NSTG == 2 || WRES, "three stages only beside resident weights");
-    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG, PT>;
+    auto kern = conv3x3_ls_k<T, MT, NLW, WRES, EM, NSTG, PT, DIR>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -610,7 +631,8 @@ static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
     char cls[96];
-    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM);
+    snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d%s>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM,
+             DIR == 2 ? ",d16" : DIR == 1 ? ",d8" : DIR == 0 ? ",gen" : "");
     const double px = (double)p.B * p.OH * p.OW;
     const int tok = sg_prof_start(cls, 2.0 * px * 9 * p.Cin * p.Cout, ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
 #ifdef SG_TRACE
@@ -710,19 +732,19 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
             SG_REQUIRE(em < 8 || em == 8 || em == 16, "conv3x3: a sign mask cannot be combined with other epilogue operands");
             static const bool no_s3 = sg_env("SRCGAN_NO_S3") != nullptr;
             if (!no_wres && !no_s3 && p.nchunk == 2) {           // Cin = 64: three 40 KiB stages + 36 KiB of weights + bias = 160 KiB
-                if (em == 0) return launch_ls<T, 1, 8, true, 0, 3>(p, 1, st);
-                if (em == 4) return launch_ls<T, 1, 8, true, 4, 3>(p, 1, st);
-                if (em == 8) return launch_ls<T, 1, 8, true, 8, 3>(p, 1, st);
-                if (em == 16) return launch_ls<T, 1, 8, true, 16, 3>(p, 1, st);
+                if (em == 0) return launch_ls<T, 1, SG_NLW1, true, 0, 3>(p, 1, st);
+                if (em == 4) return launch_ls<T, 1, SG_NLW1, true, 4, 3>(p, 1, st);
+                if (em == 8) return launch_ls<T, 1, SG_NLW1, true, 8, 3>(p, 1, st);
+                if (em == 16) return launch_ls<T, 1, SG_NLW1, true, 16, 3>(p, 1, st);
             }
             // (PT = 4: four MFMA waves with 4 rows each read 36 % fewer fragments per MFMA, but one MFMA wave per SIMD does not
-            //  keep the matrix pipe fed: 96->32 68 -> 74 us, 128->32 90 -> 98 us.  launch_ls<T, 1, 8, true, EM, 2, 4> to retry.)
+            //  keep the matrix pipe fed: 96->32 68 -> 74 us, 128->32 90 -> 98 us.  launch_ls<T, 1, SG_NLW1, true, EM, 2, 4> to retry.)
             if (!no_wres && 2 * 40 * 1024 + p.nchunk * 9 * 32 * 64 + 4096 <= 160 * 1024) {
-                if (em == 0) return launch_ls<T, 1, 8, true, 0>(p, 1, st);
-                if (em == 4) return launch_ls<T, 1, 8, true, 4>(p, 1, st);
-                if (em == 8) return launch_ls<T, 1, 8, true, 8>(p, 1, st);
-                if (em == 16) return launch_ls<T, 1, 8, true, 16>(p, 1, st);
-                return launch_ls<T, 1, 8, true, 7>(p, 1, st);
+                if (em == 0) return launch_ls<T, 1, SG_NLW1, true, 0>(p, 1, st);
+                if (em == 4) return launch_ls<T, 1, SG_NLW1, true, 4>(p, 1, st);
+                if (em == 8) return launch_ls<T, 1, SG_NLW1, true, 8>(p, 1, st);
+                if (em == 16) return launch_ls<T, 1, SG_NLW1, true, 16>(p, 1, st);
+                return launch_ls<T, 1, SG_NLW1, true, 7>(p, 1, st);
             }
             if (em == 0) return launch_ls<T, 1, SG_NLW1, false, 0>(p, 1, st);
             if (em == 4) return launch_ls<T, 1, SG_NLW1, false, 4>(p, 1, st);

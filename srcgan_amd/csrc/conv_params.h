@@ -413,9 +413,21 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 // of four 8-byte ones.  The texture addresser's time goes with the store instructions (scripts/hip/ingest_test.hip, the kernel's
 // skeleton with all three streams running: 66.6 us with the 8-byte pattern, 62.8 with this one, 62.1 with fully transposed 1-KiB
 // stores, 48.8 without stores), and it is shared with the loaders' DMA.
-template <typename T, int PT, int EM, bool X16 = false>
+// sign words of the PT output rows of lane's pixel (EM & 8), all ones where the pixel is outside the image.  The 3x3 kernel requests
+// them at the START of a unit (SG_SIGN_EARLY): requested in the epilogue, their memory latency (and the vmcnt(0) the compiler then
+// placed at the head of the next chunk loop: on gfx9 vmcnt counts the epilogue's stores too) was exposed once per unit.
+template <int PT>
+__device__ __forceinline__ void conv_direct32_sign_request(const ConvP& p, unsigned (&sgr)[PT], int b, int oy0, int ox0, int lane) {
+    const int ox = ox0 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        sgr[q] = 0xffffffffu;
+        if (ox < p.OW && oy0 + q < p.OH) sgr[q] = ((const unsigned*)p.sgn_in)[((long)b * p.OH + oy0 + q) * p.OW + ox];
+    }
+}
+template <typename T, int PT, int EM, bool X16 = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32x16 (&acc)[1][PT], const char* lds_bias,
-                                                       int b, int oy0, int ox0, int lane) {
+                                                       int b, int oy0, int ox0, int lane, const unsigned* sgpre = nullptr) {
     typedef __attribute__((ext_vector_type(4))) T vec4T;
     const int r = lane & 31, h = lane >> 5;
     const int ox = ox0 + r;
@@ -425,12 +437,21 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
     // every row's sign word is requested before the first store: vmcnt counts stores too on gfx9, a load issued after a
     // row's stores could only be waited for together with them
     unsigned sgr[PT];
+    if constexpr (PRE) {
+        // ONE unconditional wait for the words requested at the unit's start (landed long ago), in front of every store of this unit:
+        // left to the compiler, the wait for row 1's word came after row 0's stores (vmcnt retires in order -> it waited for their
+        // acknowledgement), and another one guarded the registers at the next unit's request.
+        __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
-    for (int q = 0; q < PT; ++q) {
-        sgr[q] = 0xffffffffu;
-        if ((EM & 8) && xok && oy0 + q < p.OH) sgr[q] = ((const unsigned*)p.sgn_in)[((long)b * p.OH + oy0 + q) * p.OW + ox];
+        for (int q = 0; q < PT; ++q) sgr[q] = sgpre[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            sgr[q] = 0xffffffffu;
+            if ((EM & 8) && xok && oy0 + q < p.OH) sgr[q] = ((const unsigned*)p.sgn_in)[((long)b * p.OH + oy0 + q) * p.OW + ox];
+        }
+        if (EM & 8) __builtin_amdgcn_s_waitcnt(0x0f70);
     }
-    if (EM & 8) __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int oy = oy0 + q;
