@@ -265,6 +265,11 @@ typedef struct srcgan_rddbnet_cfg {
  *                   (train.py:228-260).  Forward and backward packs are separate regions: pack the forward set in a forward
  *                   call, the backward set in a backward call.  The layout depends on the cfg's channel counts, dtype, up /
  *                   down / legacy (and for the discriminator on H, W parity), not on B, H, W.
+ *                   pack == 2 ("verify"): `guard` points at two 64-bit device words {fingerprint the pack was made from,
+ *                   fingerprint of the parameters now} (srcgan_params_fingerprint); the pack kernels run but do nothing when the
+ *                   words are equal -- the decision is taken on the device, with no host synchronisation, so weight updates the
+ *                   host cannot see (p.data.mul_(), raw-pointer writes) are still honoured.  The caller copies word 1 to word 0
+ *                   after the call.
  *   rrdb_lo/rrdb_hi rddbnet backward only.  hi <= 0: the whole backward.  Otherwise this call handles the RRDBs [lo, hi), last
  *                   to first; the call with hi == number of RRDBs also runs everything behind the trunk (conv_last, up-sampler,
  *                   trunk_conv), the call with lo == 0 everything in front of it (conv_first, dx).  Calls come in descending,
@@ -274,7 +279,12 @@ typedef struct srcgan_net_opts {
     void* wpack;
     int pack;
     int rrdb_lo, rrdb_hi;
+    const void* guard;
 } srcgan_net_opts;
+/* 64-bit order-independent fingerprint of a list of f32 tensors (every bit of every element).  table_dev: device int64
+ * [ntensors][3] = {pointer, element count, first block}; tensor t is served by the blocks [first block(t), first block(t+1)) of 65536
+ * elements each; nblocks = their total.  out_u64: one device word (zeroed and accumulated on `stream`). */
+int srcgan_params_fingerprint(const void* table_dev, int ntensors, long nblocks, void* out_u64, void* stream);
 int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);
 size_t srcgan_rddbnet_ws_bytes(const srcgan_rddbnet_cfg* c);        /* forward workspace (kept for backward) */
 size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c);

@@ -87,7 +87,7 @@ class RddbCfg(C.Structure):
 
 
 class NetOpts(C.Structure):
-    _fields_ = [("wpack", C.c_void_p), ("pack", C.c_int), ("rrdb_lo", C.c_int), ("rrdb_hi", C.c_int)]
+    _fields_ = [("wpack", C.c_void_p), ("pack", C.c_int), ("rrdb_lo", C.c_int), ("rrdb_hi", C.c_int), ("guard", C.c_void_p)]
 
 
 class ResDeconvCfg(C.Structure):
@@ -163,6 +163,7 @@ SIGNATURES = {
     "srcgan_u8rgb_to_planes": (_I, [_P, _P, _I, _L, _I, _P]),
     "srcgan_lab_planes_to_u8rgb": (_I, [_P, _P, _I, _L, _P]),
     "srcgan_adam_step": (_I, [_P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _L, _P]),
+    "srcgan_params_fingerprint": (_I, [_P, _I, _L, _P, _P]),
     "srcgan_prof_enable": (_I, [_I]),
     "srcgan_prof_collect": (_I, []),
     "srcgan_prof_get": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -124,4 +124,5 @@ struct SgPackJob {
     int cot, nchunk; long total, blk0;
 };
 void sg_pack_job_finish(SgPackJob& j, int dtype, long& blk_cursor);
-int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st);
+int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st, const unsigned long long* guard = nullptr);
+int sg_fill_zero_guarded(void* p, size_t bytes, const unsigned long long* guard, hipStream_t st);     // guard == nullptr: plain hipMemsetAsync

@@ -316,9 +316,13 @@ __global__ __launch_bounds__(256) void pack_weight_k(const float* __restrict__ w
 // 1035 composite backward packs; one launch each instead of ~1400 x 4 us).  Block b serves job j with
 // jobs[j].blk0 <= b < jobs[j+1].blk0 (binary search); destinations are offsets from `wp_base` so the table can be
 // cached across calls while the workspace moves.
+// guard: {fingerprint the pack was made from, fingerprint of the parameters now} (srcgan_params_fingerprint); equal -> the persistent
+// pack is still valid and the launch does nothing.  The decision is taken on the DEVICE: no host synchronisation, and a weight update
+// the host cannot see (p.data.mul_(), a raw-pointer write) is still noticed.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_multi_k(const SgPackJob* __restrict__ jobs, int njobs, char* wp_base) {
+__global__ __launch_bounds__(256) void pack_multi_k(const SgPackJob* __restrict__ jobs, int njobs, char* wp_base, const unsigned long long* __restrict__ guard) {
     constexpr int KCE = DT<T>::KCE;
+    if (guard && guard[0] == guard[1]) return;
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].blk0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1; }
     const SgPackJob j = jobs[lo];
@@ -347,9 +351,55 @@ void sg_pack_job_finish(SgPackJob& j, int dtype, long& blk_cursor) {
     blk_cursor += cdivl(j.total, 256);
 }
 
-int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st) {
+int sg_pack_multi_launch(const SgPackJob* jobs_dev, int njobs, long nblocks, void* wp_base, int dtype, hipStream_t st, const unsigned long long* guard) {
     if (njobs <= 0) return 0;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_multi_k<T>, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs, (char*)wp_base));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_multi_k<T>, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs, (char*)wp_base, guard));
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// zero fill that obeys the same guard as the pack it prepares (a plain memset would wipe a pack the guard then leaves alone)
+__global__ __launch_bounds__(256) void fill_zero_guarded_k(uint4* __restrict__ p, long n16, const unsigned long long* __restrict__ guard) {
+    if (guard && guard[0] == guard[1]) return;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+int sg_fill_zero_guarded(void* p, size_t bytes, const unsigned long long* guard, hipStream_t st) {
+    if (!guard) { SG_HIP(hipMemsetAsync(p, 0, bytes, st)); return 0; }
+    SG_REQUIRE(((uintptr_t)p % 16) == 0 && bytes % 16 == 0, "guarded fill: 16-byte granularity");
+    const long n16 = (long)(bytes / 16);
+    hipLaunchKernelGGL(fill_zero_guarded_k, dim3(ew_blocks(n16)), dim3(256), 0, st, (uint4*)p, n16, guard);
+    SG_LAUNCH_CHECK();
+    return 0;
+}
+
+// 64-bit fingerprint of a parameter list: sum over tensors t and elements i of mix(bits(x[t][i]), i, t).  The sum is order independent
+// (atomic adds commute), every bit of every element takes part, and a changed element changes the sum unless 2^-64 luck intervenes.
+__device__ __forceinline__ unsigned long long sg_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void params_fingerprint_k(const long* __restrict__ table, int ntens, unsigned long long* __restrict__ out) {
+    // block -> (tensor, 64 Ki-element slice of it): binary search over the table's cumulative block counts (third column)
+    int lo = 0, hi = ntens - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[3 * mid + 2] <= (long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const unsigned* p = (const unsigned*)table[3 * lo];
+    const long n = table[3 * lo + 1], i0 = ((long)blockIdx.x - table[3 * lo + 2]) * 65536;
+    const long i1 = i0 + 65536 < n ? i0 + 65536 : n;
+    const unsigned long long salt = sg_mix64(0x9E3779B97F4A7C15ull * (unsigned long long)(lo + 1));
+    unsigned long long h = 0;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) h += sg_mix64((((unsigned long long)i << 32) | p[i]) ^ salt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+extern "C" int srcgan_params_fingerprint(const void* table_dev, int ntensors, long nblocks, void* out_u64, void* stream) {
+    SG_REQUIRE(table_dev && out_u64 && ntensors > 0 && nblocks > 0, "srcgan_params_fingerprint: bad arguments");
+    SG_HIP(hipMemsetAsync(out_u64, 0, 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(params_fingerprint_k, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table_dev, ntensors, (unsigned long long*)out_u64);
     SG_LAUNCH_CHECK();
     return 0;
 }

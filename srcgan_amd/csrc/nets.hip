@@ -105,7 +105,7 @@ struct PackList {
         sg_pack_job_finish(j, dtype, nblk);
         jobs.push_back(j);
     }
-    int run(const char* tag, const void* key_ptr, void* st) {
+    int run(const char* tag, const void* key_ptr, void* st, const unsigned long long* guard = nullptr) {
         if (jobs.empty()) return 0;
         int dev = 0;
         SG_HIP(hipGetDevice(&dev));
@@ -127,9 +127,14 @@ struct PackList {
             SG_HIP(hipMemcpy(c.dev, jobs.data(), bytes, hipMemcpyHostToDevice));
             c.host = jobs;
         }
-        return sg_pack_multi_launch(c.dev, (int)jobs.size(), nblk, base, dtype, (hipStream_t)st);
+        return sg_pack_multi_launch(c.dev, (int)jobs.size(), nblk, base, dtype, (hipStream_t)st, guard);
     }
 };
+
+// opts.pack == 2: the persistent pack is re-made only if the device-side guard words differ (srcgan_net_opts)
+static inline const unsigned long long* pack_guard(const srcgan_net_opts* o) {
+    return (o && o->wpack && o->pack == 2) ? (const unsigned long long*)o->guard : nullptr;
+}
 
 // ======================================================================================== RDDBNet
 struct RddbPlan {
@@ -336,7 +341,8 @@ extern "C" int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const floa
         packs.add(params[P.p_lg[k]], wp + P.lw_f[k], nf, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
     packs.add(params[P.p_last_w], wp + P.w_last_f, c->out_ch, nf, 3, 3, (long)nf * 9, 9, 3, 1, 0);
 
-    if (do_pack) SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : P.legacy == 3 ? "srdn_fwd" : "rddb_fwd", params[0], st));
+    SG_REQUIRE(!(opt && opt->pack == 2) || (opt->wpack && opt->guard), "srcgan_rddbnet_forward: pack == 2 needs wpack and guard");
+    if (do_pack) SG_TRY(packs.run(P.legacy == 1 ? "rddbB_fwd" : P.legacy == 2 ? "rddbL_fwd" : P.legacy == 3 ? "srdn_fwd" : "rddb_fwd", params[0], st, pack_guard(opt)));
 
     // ---- input: NCHW f32 -> NHWC (channels zero-padded to 8)
     SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -468,7 +474,7 @@ extern "C" int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const flo
         for (int k = 0; k < P.nlw; ++k)
             packs.add(params[P.p_lg[k]], wp + P.lw_d[k], nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
         if (P.legacy != 3) packs.add(params[P.p_trunk_w], wp + P.w_trunk_d, nf, nf, 3, 3, L.sr, L.sk, L.sty, L.stx, L.off);
-        SG_HIP(hipMemsetAsync(wp + P.w_rdb_d0, 0, P.w_rdb_dsz, (hipStream_t)st));
+        SG_TRY(sg_fill_zero_guarded(wp + P.w_rdb_d0, P.w_rdb_dsz, pack_guard(opt), (hipStream_t)st));
         for (int r = 0; r < P.nrr * 3; ++r) {
             const float a5 = (r % 3 == 2) ? 0.04f : 0.2f;       // d(x5)/d(block out), RDB3 carries the RRDB 0.2 too
             for (int j = 0; j < 5; ++j) {
@@ -495,7 +501,7 @@ extern "C" int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const flo
         }
         SG_TRY(packs.run(P.legacy == 1 ? (pack_dx ? "rddbB_bwd_dx" : "rddbB_bwd") : P.legacy == 2 ? (pack_dx ? "rddbL_bwd_dx" : "rddbL_bwd")
                                        : P.legacy == 3 ? (pack_dx ? "srdn_bwd_dx" : "srdn_bwd")
-                                       : (pack_dx ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st));
+                                       : (pack_dx ? "rddb_bwd_dx" : "rddb_bwd"), params[0], st, pack_guard(opt)));
     }
 
     // ---- dy: NCHW f32 -> NHWC
@@ -825,14 +831,14 @@ extern "C" int srcgan_nlayerd_forward_ex(const srcgan_nlayerd_cfg* c, const floa
         for (int l = 0; l < P.L; ++l) {
             if (l == 0 && P.s2d) {
                 // W[co][c][2ty+dy][2tx+dx] -> k = (dy,dx,c8), taps (ty,tx): one part per (dy,dx); channels c >= Cin stay zero
-                SG_HIP(hipMemsetAsync(wp + P.wf[0], 0, srcgan_packed_weight_bytes(P.ch[1], 32, 4, dt), (hipStream_t)st));
+                SG_TRY(sg_fill_zero_guarded(wp + P.wf[0], srcgan_packed_weight_bytes(P.ch[1], 32, 4, dt), pack_guard(opt), (hipStream_t)st));
                 for (int q = 0; q < 4; ++q)
                     packs.add(params[P.pw[0]], wp + P.wf[0], P.ch[1], P.ch[0], 2, 2, (long)P.ch[0] * 16, 16, 8, 2, (q >> 1) * 4 + (q & 1), q * 8, 32);
                 continue;
             }
             packs.add(params[P.pw[l]], wp + P.wf[l], P.ch[l + 1], P.ch[l], 4, 4, (long)P.ch[l] * 16, 16, 4, 1, 0);
         }
-        SG_TRY(packs.run(P.s2d ? "d_fwd_s2d" : "d_fwd", params[0], st));
+        SG_TRY(packs.run(P.s2d ? "d_fwd_s2d" : "d_fwd", params[0], st, pack_guard(opt)));
     }
     if (P.s2d) SG_TRY(srcgan_nchw_f32_to_s2d(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, dt, st));
     else SG_TRY(srcgan_nchw_f32_to_nhwc(x_nchw, w8 + P.xin, B, c->in_ch, c->H, c->W, P.in_cs, dt, st));
@@ -898,7 +904,7 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
             // The rows of one (dy,dx) are a strided slice of the weight: one part per (dy,dx) and per half of k (so that no part
             // is a whole matrix, which would zero-fill all 32 rows of its view), written at row offset (dy*2+dx)*8.
             const int kce = 64 / P.esz;
-            SG_HIP(hipMemsetAsync(wp + P.wd[0][0], 0, srcgan_packed_weight_bytes(32, cout, 4, dt), (hipStream_t)st));
+            SG_TRY(sg_fill_zero_guarded(wp + P.wd[0][0], srcgan_packed_weight_bytes(32, cout, 4, dt), pack_guard(opt), (hipStream_t)st));
             for (int q = 0; q < 4; ++q)
                 for (int hk = 0; hk < 2; ++hk)
                     packs.add(params[P.pw[0]], wp + P.wd[0][0] + (size_t)q * 8 * kce * P.esz, cin, cout / 2, 2, 2, 16, (long)cin * 16, -8, -2,
@@ -914,7 +920,7 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
                 packs.add(params[P.pw[l]], wp + P.wd[l][q], cin, cout, 2, 2, 16, (long)cin * 16, -8, -2, off);
             }
     }
-    SG_TRY(packs.run(P.s2d ? (pack_dx ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (pack_dx ? "d_bwd_dx" : "d_bwd"), params[0], st));
+    SG_TRY(packs.run(P.s2d ? (pack_dx ? "d_bwd_dx_s2d" : "d_bwd_s2d") : (pack_dx ? "d_bwd_dx" : "d_bwd"), params[0], st, pack_guard(opt)));
     // ---- dy -> NHWC (1 channel, padded with zeros to 8)
     const int Lh = P.hh[P.L], Lw = P.ww[P.L];
     TRef dcur = tref(s8 + Q.dO, P.out_cs);

@@ -82,34 +82,56 @@ def _kaiming_like_reference(module: nn.Module) -> None:
 class _PackState:
     """Persistent packed (MFMA-order, compute-dtype) copy of a module's weights: packed once per weight update instead of once per
     native call -- a cycle step runs each generator three times forward and three times backward on the same weights
-    (reference train.py:228-260, 331-333).  Validity is keyed on the parameters' autograd version counters (every in-place
-    update bumps them: load_state_dict, broadcast, torch optimisers; srcgan_amd.optim.Adam's native step bumps them
-    explicitly), their addresses and the layout-relevant part of the configuration."""
+    (reference train.py:228-260, 331-333).
+
+    Validity is decided ON THE DEVICE, per call and without a host synchronisation: ``srcgan_params_fingerprint`` hashes every bit
+    of every parameter (66 MB for the 23-block generator: ~15 us) into the second word of a guard pair, and the pack kernels of
+    the native call do nothing when it equals the first word -- the fingerprint the pack was made from (``srcgan_net_opts.pack
+    == 2``).  So ANY way of changing the weights is honoured: optimiser steps, ``load_state_dict``, ``p.data.mul_()`` (which does
+    not bump autograd's version counter), a raw-pointer write by another library.  The host only forces a pack when the buffer is
+    new, the layout changed or the parameters moved (their pointer table is rebuilt then); ``invalidate()`` forces one too."""
 
     def __init__(self):
         self.buf = None
-        self.fwd_key = None
-        self.bwd_key = None
+        self.layout = None
+        self.table = None            # device int64 [n, 3]: pointer, elements, first fingerprint block
+        self.table_key = None
+        self.nblocks = 0
+        self.guard = None            # device int64 [4]: forward {packed-from, now}, backward {packed-from, now}
+        self.valid = [False, False]  # forward / backward pack made at least once from the current buffer + table
 
-    @staticmethod
-    def key(params, extra):
-        return (sum(p._version for p in params), params[0].data_ptr(), params[-1].data_ptr(), len(params), extra)
+    def invalidate(self):
+        """Force the next forward and the next backward to re-pack (never needed for correctness: see the class comment)."""
+        self.valid = [False, False]
 
     def opts(self, lib_bytes_fn, cfg, params, extra, backward, device):
-        """-> (NetOpts, keepalive).  Allocates / re-packs as needed."""
-        k = self.key(params, extra)
+        """-> NetOpts for one native call.  Call ``done(backward)`` after the call succeeded."""
         need = int(lib_bytes_fn(C.byref(cfg)))
-        if self.buf is None or self.buf.numel() < need or self.buf.device != device or getattr(self, "layout", None) != extra:
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device or self.layout != extra:
             self.buf = torch.empty(need, dtype=torch.uint8, device=device)
-            self.fwd_key = self.bwd_key = None
+            self.guard = torch.zeros(4, dtype=torch.int64, device=device)
             self.layout = extra
-        if backward:
-            pack = self.bwd_key != k
-            self.bwd_key = k
-        else:
-            pack = self.fwd_key != k
-            self.fwd_key = k
-        return N.NetOpts(self.buf.data_ptr(), int(pack), 0, 0)
+            self.valid = [False, False]
+        key = tuple((p.data_ptr(), p.numel()) for p in params)
+        if key != self.table_key:
+            rows, blk = [], 0
+            for ptr, n in key:
+                rows.append((ptr, n, blk))
+                blk += (n + 65535) // 65536
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.table_key, self.nblocks = key, blk
+            self.valid = [False, False]
+        slot = 2 if backward else 0
+        gptr = self.guard.data_ptr() + 8 * slot
+        N.check(N.lib().srcgan_params_fingerprint(self.table.data_ptr(), len(key), self.nblocks, gptr + 8, N.stream_ptr(device)),
+                "srcgan_params_fingerprint")
+        return N.NetOpts(self.buf.data_ptr(), 2 if self.valid[1 if backward else 0] else 1, 0, 0, gptr)
+
+    def done(self, backward):
+        """The native call that packed (or verified) returned without error: what is packed now matches the fingerprint."""
+        slot = 2 if backward else 0
+        self.guard[slot:slot + 1].copy_(self.guard[slot + 1:slot + 2])
+        self.valid[1 if backward else 0] = True
 
 
 class _GradArena:
@@ -161,6 +183,8 @@ class _RddbFn(torch.autograd.Function):
         opt = pstate.opts(lib.srcgan_rddbnet_wpack_bytes, cfg, plist, layout, False, x.device) if pstate is not None else None
         N.check(lib.srcgan_rddbnet_forward_ex(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), ws.data_ptr(), y.data_ptr(),
                                               C.byref(opt) if opt is not None else None, N.stream_ptr(x.device)), "srcgan_rddbnet_forward")
+        if pstate is not None:
+            pstate.done(False)
         ctx.cfg, ctx.ws, ctx.n = cfg, ws, len(plist)
         ctx.pstate, ctx.layout = pstate, layout
         ctx.save_for_backward(*plist)
@@ -183,7 +207,7 @@ class _RddbFn(torch.autograd.Function):
         scratch = N.workspace(lib.srcgan_rddbnet_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         dx = torch.empty(cfg.B, cfg.in_ch, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
         pstate = ctx.pstate
-        opt = pstate.opts(lib.srcgan_rddbnet_wpack_bytes, cfg, params, ctx.layout, True, dy.device) if pstate is not None else N.NetOpts(None, 0, 0, 0)
+        opt = pstate.opts(lib.srcgan_rddbnet_wpack_bytes, cfg, params, ctx.layout, True, dy.device) if pstate is not None else N.NetOpts(None, 0, 0, 0, None)
         gptr, pptr = N.ptr_array(grads), N.ptr_array(params)
         hook = ctx.phase_hook
         nrr = 0 if cfg.legacy == 2 else (2 * cfg.nb if cfg.legacy == 3 else cfg.nb)
@@ -197,6 +221,8 @@ class _RddbFn(torch.autograd.Function):
             N.check(lib.srcgan_rddbnet_backward_ex(C.byref(cfg), dy.data_ptr(), pptr, ctx.ws.data_ptr(), scratch.data_ptr(), gptr,
                                                    dx.data_ptr() if need_dx else None, C.byref(opt), N.stream_ptr(dy.device)),
                     "srcgan_rddbnet_backward")
+            if opt.pack and pstate is not None:
+                pstate.done(True)
             opt.pack = 0
             if hook is not None:
                 hook.phase_done(arena, params, cfg, lo, hi, nrr)
@@ -236,6 +262,11 @@ class RDDBNet(nn.Module):
 
     def _down(self):
         return 0
+
+    def invalidate_packed_weights(self):
+        """Force a re-pack of the kernels' weight copy at the next forward / backward.  Not needed for correctness -- every native
+        call verifies the copy against a device-side fingerprint of the parameters (see _PackState) -- kept as an explicit hook."""
+        self._pack.invalidate()
 
     def forward(self, x):
         cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self._down(), 0, self._pack)
@@ -640,6 +671,7 @@ class _NLayerDFn(torch.autograd.Function):
         N.check(lib.srcgan_nlayerd_forward_ex(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), N.ptr_array(running),
                                               N.ptr_array(nbt), ws.data_ptr(), y.data_ptr(), C.byref(opt), N.stream_ptr(x.device)),
                 "srcgan_nlayerd_forward")
+        pstate.done(False)
         ctx.cfg, ctx.ws = cfg, ws
         ctx.pstate, ctx.layout = pstate, layout
         ctx.save_for_backward(*plist)
@@ -664,6 +696,7 @@ class _NLayerDFn(torch.autograd.Function):
         N.check(lib.srcgan_nlayerd_backward_ex(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(),
                                                scratch.data_ptr(), N.ptr_array(grads), dx.data_ptr() if need_dx else None,
                                                C.byref(opt), N.stream_ptr(dy.device)), "srcgan_nlayerd_backward")
+        ctx.pstate.done(True)
         ctx.ws = None
         if ctx.phase_hook is not None and arena is not None:
             ctx.phase_hook.phase_done(arena, params, cfg, 0, 0, 0)
@@ -695,6 +728,10 @@ class NLayerDiscriminator(nn.Module):
         self._cfg = (input_nc, ndf, n_layers)
         self.compute_dtype = N.dtype_name(dtype)
         self._pack = _PackState()
+
+    def invalidate_packed_weights(self):
+        """See RDDBNet.invalidate_packed_weights."""
+        self._pack.invalidate()
 
     def forward(self, input):
         bns = [m for m in self.model if isinstance(m, nn.BatchNorm2d)]

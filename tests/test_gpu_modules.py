@@ -617,3 +617,60 @@ def test_empty_batch_generator():
     assert tuple(y.shape) == (0, 3, 32, 48)
     y.sum().backward()
     assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
+
+
+@pytest.mark.parametrize("kind", ["generator", "discriminator"])
+def test_packed_weights_follow_every_kind_of_weight_update(kind):
+    """The kernels read a persistent packed copy of the weights (model._PackState).  It must follow EVERY way the weights can
+    change between two calls -- also the ones autograd's version counters do not see (``p.data.mul_``: the reference's
+    ``m.weight.data *= scale`` idiom) -- and must not be re-used across ``load_state_dict`` / a replaced parameter.  Checked
+    against the CPU oracle evaluated on the CURRENT state_dict each time: output and every weight gradient."""
+    import srcgan_amd
+    torch.manual_seed(5)
+    if kind == "generator":
+        net = srcgan_amd.RDDBNet(3, 3, 2, nf=32, nb=1, gc=16, dtype="fp32").cuda()
+        x = torch.rand(2, 3, 12, 10)
+        ofwd = lambda sd: oracle.rddbnet_forward(sd, x, 2)
+    else:
+        net = srcgan_amd.NLayerDiscriminator(3, 16, 3, dtype="fp32").cuda()
+        x = torch.rand(2, 3, 32, 32)
+        ofwd = lambda sd: oracle.nlayer_d_forward(sd, x, training=True)
+    net.train()
+
+    def check(what):
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        names = [n for n, _ in net.named_parameters()]
+        for n in names:
+            sd[n].requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        y = net(x.cuda())
+        y.square().sum().backward()
+        yr = ofwd(sd)
+        yr.square().sum().backward()
+        assert rel_err(y.detach().cpu(), yr.detach()) < F32_TOL, what
+        for n, p in net.named_parameters():
+            assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, f"{what}: {n}"
+        return y.detach().cpu()
+
+    y0 = check("initial")
+    with torch.no_grad():
+        for p in net.parameters():
+            p.data.mul_(0.5)                       # invisible to the version counter
+    y1 = check("after p.data.mul_")
+    assert rel_err(y1, y0) > 1e-2                  # the output did change
+    first = next(net.parameters())
+    first.data.copy_(first.data.flip(0))           # .data.copy_ of one tensor only
+    check("after p.data.copy_")
+    sd2 = {k: (v.detach().cpu() * 1.5 if v.is_floating_point() else v.detach().cpu()) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd2)
+    check("after load_state_dict")
+    with torch.no_grad():                          # a parameter replaced by a new tensor (new address, version 0)
+        name, old = next(iter(net.named_parameters()))
+        mod = net
+        for part in name.split(".")[:-1]:
+            mod = getattr(mod, part)
+        setattr(mod, name.split(".")[-1], torch.nn.Parameter((old * 0.25).clone()))
+    check("after replacing a parameter")
+    net.invalidate_packed_weights()
+    check("after invalidate_packed_weights")
