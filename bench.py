@@ -222,8 +222,9 @@ def launch_ranks(n):
     import subprocess
     import tempfile
     if os.environ.get("SRCGAN_LOCAL_DEVICE") is None:        # (rehearsal on one device: tests/test_gpu_dist.py)
-        have = torch.cuda.device_count()                      # counting devices does not initialise HIP
-        if have < n:
+        from srcgan_amd.dist import visible_gpu_count
+        have = visible_gpu_count()                            # visibility variables / the KFD topology in sysfs: the HIP runtime stays closed
+        if 0 <= have < n:                                     # (-1: no topology readable here -- the ranks find out)
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -369,10 +370,15 @@ def main():
     torch.manual_seed(0)                         # identical init on every rank, then broadcast anyway
     step, nets, harness, per_img_mac, workload, losses = build(args, dev, rank)
     use_dist = world > 1 or dist.is_initialized()          # one rank + SRCGAN_FORCE_DIST=1 rehearses the RCCL path
+    dinfo, gsync = None, None
     if use_dist:
         for net in nets:
             sdist.broadcast_module(net)
-        harness.grad_sync = sdist.GradSync().attach()       # gradients are averaged inside every native backward call
+        # one-call-per-step networks: averaged inside their backward call (generator: 4 overlapped phases); networks that run
+        # several times per step accumulate and exchange once in front of optimizer.step() (harness._once)
+        gsync = sdist.GradSync().attach()
+        harness.grad_sync = gsync
+        dinfo = sdist.dist_info(dev)
     B = args.batch
 
     def barrier():
@@ -433,8 +439,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "gradient_exchange": ("RCCL all-reduce of flat gradient arenas inside every native backward; generator backward in 4 RRDB-range "
-                                             "phases, each phase's slice reduced on a side stream while the next computes") if use_dist else "none (1 rank)"},
+                       "gradient_exchange": (f"{dinfo['backend']} all-reduce over {dinfo['world_size']} rank(s) of flat f32 gradient arenas, in place: networks that run "
+                                             "once per step inside their native backward (generator: 4 RRDB-range phases on a side stream, overlapped); "
+                                             "networks that run several times per step once, accumulated, in front of optimizer.step()") if use_dist else "none (1 rank)"},
+            "dist": None if not use_dist else {**dinfo, "grad_sync": dict(gsync.stats), "steps_counted": args.warmup + args.steps + (0 if args.no_kernel_profile else 1),
+                                                "param_bytes": sum(p.numel() * 4 for net in nets for p in net.parameters())},
             "algorithmic_tflop_per_image": 2 * per_img_mac / 1e12,
             "step_tflops": 2 * per_img_mac * imgs / elapsed / 1e12,
             "peak_memory_gb": round(peak_gb, 2),

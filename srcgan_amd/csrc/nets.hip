@@ -89,7 +89,7 @@ static int bias_grad(int dtype, TRef dy, long npix, int C, float scale, float* o
 }
 
 // ---- batched weight packing with a cached device-side job table
-struct PackCache { std::vector<SgPackJob> host; SgPackJob* dev = nullptr; size_t cap = 0; };
+struct PackCache { std::vector<SgPackJob> host; SgPackJob* dev = nullptr; SgPackJob* pinned = nullptr; size_t cap = 0; hipEvent_t staged = nullptr; };
 static std::map<std::string, PackCache> g_pack_cache;
 static std::mutex g_pack_mutex;
 
@@ -115,16 +115,24 @@ struct PackList {
         PackCache& c = g_pack_cache[key];
         const size_t bytes = jobs.size() * sizeof(SgPackJob);
         if (c.host.size() != jobs.size() || memcmp(c.host.data(), jobs.data(), bytes) != 0) {
-            // cold path (first call / parameters or buffers moved): an earlier pack kernel on this stream may still be reading
-            // the table, so the stream is drained before the table is replaced (a blocking copy alone orders nothing
-            // against a non-blocking stream)
-            SG_HIP(hipStreamSynchronize((hipStream_t)st));
+            // cold path (first call / parameters or buffers moved).  The table is staged in pinned memory and copied on the
+            // call's stream: stream order puts the copy behind every earlier pack kernel that still reads the old table and in
+            // front of this call's -- no host synchronisation.  Only a table that outgrows its buffers allocates (first call,
+            // behind a stream drain: the old device table may still be in use), and a second re-staging waits for the first
+            // one's copy to have left the pinned buffer.
             if (c.cap < bytes) {
+                SG_HIP(hipStreamSynchronize((hipStream_t)st));
                 if (c.dev) SG_HIP(hipFree(c.dev));
+                if (c.pinned) SG_HIP(hipHostFree(c.pinned));
                 SG_HIP(hipMalloc((void**)&c.dev, bytes));
+                SG_HIP(hipHostMalloc((void**)&c.pinned, bytes, hipHostMallocDefault));
                 c.cap = bytes;
             }
-            SG_HIP(hipMemcpy(c.dev, jobs.data(), bytes, hipMemcpyHostToDevice));
+            if (!c.staged) SG_HIP(hipEventCreateWithFlags(&c.staged, hipEventDisableTiming));
+            else SG_HIP(hipEventSynchronize(c.staged));
+            memcpy(c.pinned, jobs.data(), bytes);
+            SG_HIP(hipMemcpyAsync(c.dev, c.pinned, bytes, hipMemcpyHostToDevice, (hipStream_t)st));
+            SG_HIP(hipEventRecord(c.staged, (hipStream_t)st));
             c.host = jobs;
         }
         return sg_pack_multi_launch(c.dev, (int)jobs.size(), nblk, base, dtype, (hipStream_t)st, guard);

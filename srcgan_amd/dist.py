@@ -10,9 +10,13 @@ all-reduced in place on a side stream (<= bucket_mb pieces: few, large collectiv
 point-to-point, ring steps are per-link bound) while the next phase computes on the main stream.  What
 autograd receives from ``backward`` is already the mean over replicas, so the harnesses need no separate
 synchronisation step and a network called several times per step (the cycle's generators, train.py:228-260)
-simply averages each contribution.  BatchNorm statistics stay per replica (no SyncBN), as single-device
-reference semantics imply.  ``GradSync.allreduce(params)`` is the plain post-backward form (bucketed,
-asynchronous, flatten + copy-back) for anything that is not one of this package's networks.
+needs one reduce per backward call.  A network that runs SEVERAL times per optimiser step (the cycle's generators,
+train.py:228-260: three passes each; a discriminator's real + fake pass; StackedSR's micro-batches) is registered with
+``GradSync.once(module)``: its backward calls then only accumulate locally, and ``GradSync.sync(params)`` -- what every harness
+calls in front of ``optimizer.step()`` -- reduces the ACCUMULATED gradient once, in place in the flat arena the ``.grad``s alias
+(one parameter-sized exchange per network and step instead of one per call; the mean is linear, so the result is the same).
+BatchNorm statistics stay per replica (no SyncBN), as single-device reference semantics imply.  ``GradSync.allreduce(params)`` is
+the plain post-backward form (bucketed, asynchronous, flatten + copy-back) for anything that is not one of this package's networks.
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "broadcast_module", "GradSync", "shard_range"]
+__all__ = ["init_from_env", "broadcast_module", "GradSync", "shard_range", "dist_info", "visible_gpu_count"]
 
 
 # SRCGAN_FORCE_DIST=1: create the process group and run the collectives even with one rank (rehearses the RCCL path --
@@ -51,6 +55,45 @@ def init_from_env(backend: Optional[str] = None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT opening the HIP runtime (a launcher that then starts one process per GPU stays GPU-free):
+    the visibility lists HIP honours if set, else the nodes the kernel driver (KFD) lists with a non-zero SIMD count; -1 = unknown."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n, root = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(line.split(None, 1) for line in f if " " in line)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return -1                # no KFD topology readable here: unknown (the ranks themselves will find out)
+    return n
+
+
+def dist_info(device=None) -> dict:
+    """What the process group really is -- for the bench line: backend, world size, the number of ranks an all-reduce of ones
+    actually saw (proves the collective crossed every rank), and the RCCL/NCCL version when the backend is 'nccl'."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "ranks_seen": 1, "nccl_version": None}
+    backend = dist.get_backend()
+    one = torch.ones(1, device=device if (device is not None and backend == "nccl") else "cpu" if backend == "gloo" else device)
+    dist.all_reduce(one)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # pragma: no cover
+            ver = "unknown"
+    return {"backend": backend, "world_size": dist.get_world_size(), "ranks_seen": int(round(float(one.item()))), "nccl_version": ver}
 
 
 def shard_range(n_units: int, rank: int, world: int):
@@ -94,15 +137,31 @@ class GradSync:
         self.phases = max(1, int(phases))
         self.attached = False
         self.stats = {"calls": 0, "phases": 0, "collectives": 0, "bytes": 0}
+        self._once_ptrs = set()      # data_ptr of every parameter of a network registered with once()
 
     # ---- in-backward form -------------------------------------------------------------------------------------------
     def attach(self) -> "GradSync":
-        """Average gradients inside every native backward of this package's networks (see the module docstring)."""
+        """Average gradients inside every native backward of this package's networks (see the module docstring).  The hook table
+        is process-wide: a second GradSync cannot be attached while another one is."""
         from . import model
+        other = [h for h in model._phase_hooks.values() if h is not self]
+        if other:
+            raise RuntimeError("srcgan_amd.dist: another GradSync is attached; detach() it first (the backward hooks are process-wide)")
         for kind in ("rddb", "nlayerd", "resdeconv", "srnet"):
             model._phase_hooks[kind] = self
         self.attached = True
         return self
+
+    def once(self, *modules) -> "GradSync":
+        """Networks that run several times per optimiser step: their native backward calls do not reduce; ``sync(params)`` reduces
+        the accumulated gradient once.  (Parameters are identified by address: call again after moving a module.)"""
+        for m in modules:
+            if m is not None:
+                self._once_ptrs.update(p.data_ptr() for p in m.parameters())
+        return self
+
+    def _deferred(self, params) -> bool:
+        return len(params) > 0 and params[0].data_ptr() in self._once_ptrs
 
     def detach(self) -> None:
         from . import model
@@ -111,10 +170,10 @@ class GradSync:
                 del model._phase_hooks[kind]
         self.attached = False
 
-    def cuts(self, cfg, nrr: int) -> List[int]:
+    def cuts(self, cfg, nrr: int, params=()) -> List[int]:
         """Phase boundaries (RRDB indices) of a generator backward: ``phases`` near-equal RRDB ranges.  Only the plain RDDBNet /
         RDDBNetA parameter order (conv_first, [down], RRDBs, trunk_conv, up-sampler, conv_last) is phased."""
-        if not self._active or cfg.legacy != 0 or nrr < 2:
+        if not self._active or cfg.legacy != 0 or nrr < 2 or self._deferred(params):
             return [0]
         k = min(self.phases, nrr)
         return sorted({(nrr * j) // k for j in range(k)})
@@ -123,7 +182,7 @@ class GradSync:
     def phase_done(self, arena, params, cfg, lo: int, hi: int, nrr: int) -> None:
         """The native call that finalised the gradients of RRDBs [lo, hi) (+ tail if hi == nrr, + head if lo == 0; everything when
         nrr == 0) has been queued on the current stream: reduce that slice of the arena on the side stream, in place."""
-        if not self._active or arena is None or arena.flat.numel() == 0:
+        if not self._active or arena is None or arena.flat.numel() == 0 or self._deferred(params):
             return
         n = len(params)
         if nrr > 0 and not (lo == 0 and hi == nrr):
@@ -157,6 +216,53 @@ class GradSync:
             if cuda:
                 main.wait_stream(self._side)                  # autograd / the optimiser see averaged gradients
                 flat.record_stream(self._side)
+
+    # ---- once per optimiser step ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sync(self, params: Iterable[torch.nn.Parameter]) -> None:
+        """Make the ``.grad``s of ``params`` the mean over replicas, whatever is still missing: nothing for networks whose backward
+        already averaged them (attached, one call per step); ONE reduce of the accumulated gradient for the others -- in place in
+        the flat arena the gradients alias when they do (model._GradArena: autograd adopts the first call's views and accumulates
+        later calls into them), through flattened buckets otherwise."""
+        if not self._active:
+            return
+        todo = [p for p in params if p.grad is not None and not (self.attached and p.data_ptr() not in self._once_ptrs)]
+        if not todo:
+            return
+        groups = {}
+        for p in todo:
+            g = p.grad
+            groups.setdefault(g.untyped_storage().data_ptr() if g.is_contiguous() else -id(g), []).append(p)
+        rest, flats = [], []
+        for key, ps in groups.items():
+            gs = [p.grad for p in ps]
+            lo = min(g.storage_offset() for g in gs)
+            hi = max(g.storage_offset() + g.numel() for g in gs)
+            if key < 0 or len(ps) < 2 or sum(g.numel() for g in gs) != hi - lo or any(g.dtype != gs[0].dtype for g in gs):
+                rest += ps                                   # not one gap-free arena: flatten
+            else:
+                flats.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (hi - lo,), (1,)))
+        for flat in flats:
+            cuda = flat.is_cuda
+            main = torch.cuda.current_stream(flat.device) if cuda else None
+            if cuda:
+                self._side.wait_stream(main)
+            with self._ctx(cuda):
+                step = max(1, self.bucket_bytes // flat.element_size())
+                for o in range(0, flat.numel(), step):
+                    piece = flat[o:o + step]
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                    piece.mul_(1.0 / self.world)
+                    self.stats["collectives"] += 1
+                    self.stats["bytes"] += piece.numel() * piece.element_size()
+            if cuda:
+                main.wait_stream(self._side)
+                flat.record_stream(self._side)
+        if rest:
+            before = sum(p.grad.numel() * p.grad.element_size() for p in rest)
+            self.allreduce(rest)
+            self.stats["bytes"] += before
+        self.stats["calls"] += 1
 
     def _buckets(self, grads: List[torch.Tensor]) -> List[List[torch.Tensor]]:
         out, cur, size = [], [], 0

@@ -212,7 +212,7 @@ class _RddbFn(torch.autograd.Function):
         hook = ctx.phase_hook
         nrr = 0 if cfg.legacy == 2 else (2 * cfg.nb if cfg.legacy == 3 else cfg.nb)
         # phases: RRDB ranges, last to first (one phase unless a data-parallel hook asks for more)
-        cuts = hook.cuts(cfg, nrr) if (hook is not None and nrr > 1) else [0]
+        cuts = hook.cuts(cfg, nrr, params) if (hook is not None and nrr > 1) else [0]
         hi = nrr
         for lo in sorted(set(cuts) | {0}, reverse=True):
             if lo >= hi and hi != nrr:
@@ -400,6 +400,7 @@ class _ResDeconvFn(torch.autograd.Function):
                                              N.stream_ptr(x.device)), "srcgan_resdeconv_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(*plist)
+        ctx.phase_hook = _phase_hooks.get("resdeconv")       # one rule for every network: the hook in force at FORWARD time
         return y
 
     @staticmethod
@@ -418,8 +419,8 @@ class _ResDeconvFn(torch.autograd.Function):
         N.check(lib.srcgan_resdeconv_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
                                               N.ptr_array(grads), dx.data_ptr() if need_dx else None, N.stream_ptr(dy.device)), "srcgan_resdeconv_backward")
         ctx.ws = None
-        if _phase_hooks.get("resdeconv") is not None:
-            _phase_hooks["resdeconv"].phase_done(arena, params, cfg, 0, 0, 0)
+        if ctx.phase_hook is not None:
+            ctx.phase_hook.phase_done(arena, params, cfg, 0, 0, 0)
         return (dx, None, None, *grads)
 
 
@@ -440,13 +441,19 @@ class _BasicBlockHolder(_HolderOnly):
 
 class ResDeconv(nn.Module):
     """Colouriser, drop-in for reference ``model.ResDeconv`` (src/model/resdeconv.py:99-195, BN='GN', layers=[2,2,2,2]):
-    ``ResDeconv(src_ch=1, tar_ch=3)``; ``forward(x[B,src_ch,H,W]) -> [B,tar_ch,H,W]`` (H, W multiples of 16).
+    ``ResDeconv(src_ch=1, tar_ch=3, block=None, layers=[2, 2, 2, 2], BN='GN')`` -- the reference's positional signature
+    (resdeconv.py:107); the native kernels implement its defaults (BasicBlock, ResNet-18 layout, GroupNorm(32)), anything else
+    is refused.  ``forward(x[B,src_ch,H,W]) -> [B,tar_ch,H,W]`` (H, W multiples of 16).
     A 1-channel source is replicated to 3 channels like the reference (resdeconv.py:166-167)."""
 
-    def __init__(self, src_ch=1, tar_ch=3, layers=(2, 2, 2, 2), dtype=None):
+    def __init__(self, src_ch=1, tar_ch=3, block=None, layers=(2, 2, 2, 2), BN="GN", dtype=None):
         super().__init__()
+        if block is not None and getattr(block, "__name__", str(block)) not in ("BasicBlock", "_BasicBlockHolder"):
+            raise NotImplementedError("native ResDeconv implements the reference default block=BasicBlock")
         if list(layers) != [2, 2, 2, 2]:
             raise NotImplementedError("native ResDeconv implements the reference default layers=[2, 2, 2, 2]")
+        if BN != "GN":
+            raise NotImplementedError("native ResDeconv implements the reference default BN='GN' (GroupNorm(32, C))")
         self.src_ch = src_ch
         if isinstance(tar_ch, list):
             tar_ch = sum(tar_ch)
@@ -519,6 +526,7 @@ class _SrNetFn(torch.autograd.Function):
                 "srcgan_srnet_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(*plist)
+        ctx.phase_hook = _phase_hooks.get("srnet")
         return y
 
     @staticmethod
@@ -537,8 +545,8 @@ class _SrNetFn(torch.autograd.Function):
         N.check(lib.srcgan_srnet_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
                                           N.ptr_array(grads), dx.data_ptr() if need_dx else None, N.stream_ptr(dy.device)), "srcgan_srnet_backward")
         ctx.ws = None
-        if _phase_hooks.get("srnet") is not None:
-            _phase_hooks["srnet"].phase_done(arena, params, cfg, 0, 0, 0)
+        if ctx.phase_hook is not None:
+            ctx.phase_hook.phase_done(arena, params, cfg, 0, 0, 0)
         return (dx, None, *grads)
 
 

@@ -39,7 +39,34 @@ def set_requires_grad(nets, requires_grad=False):
                 p.requires_grad = requires_grad
 
 
-class PairedSRGAN:
+class _DataParallel:
+    """``harness.grad_sync = GradSync()[.attach()]`` makes a harness data parallel (srcgan_amd.dist).  ``_once`` names the networks
+    that run SEVERAL times per optimiser step: their backward calls only accumulate and ``_sync(params)`` -- called in front of
+    every ``optimizer.step()`` -- exchanges the accumulated gradient ONCE; the others are averaged inside their single backward
+    call when the GradSync is attached (phased, overlapped), or here when it is not."""
+    _once = ()
+    _grad_sync = None
+
+    @property
+    def grad_sync(self):
+        return self._grad_sync
+
+    @grad_sync.setter
+    def grad_sync(self, sync):
+        self._grad_sync = sync
+        if sync is not None:
+            nets = []
+            for name in self._once:
+                v = getattr(self, name)
+                nets += list(v) if isinstance(v, (list, tuple)) else [v]
+            sync.once(*nets)
+
+    def _sync(self, params):
+        if self._grad_sync is not None:
+            self._grad_sync.sync(list(params))
+
+
+class PairedSRGAN(_DataParallel):
     """G-step: fake=G(x); loss_G = lsgan(D(fake), real) + lambda_l1 * L1(fake, y)   (D frozen, train.py:330)
     D-step: loss_D = 0.5 * (lsgan(D(y), real) + lsgan(D(fake.detach()), fake))      (train.py:262-280)
     Adam(G: 1e-4, D: 1e-5, betas (0.5, 0.999)) as train.py:191-192."""
@@ -54,14 +81,11 @@ class PairedSRGAN:
         self.lambda_l1 = lambda_l1
         self.optimizer_G = Adam(self.netG.parameters(), lr=lr_g, betas=(beta1, 0.999))      # a torch.optim.Adam with a fused step()
         self.optimizer_D = Adam(self.netD.parameters(), lr=lr_d, betas=(beta1, 0.999))
-        # Data parallel: srcgan_amd.dist.GradSync.  Attached (``GradSync().attach()``, what bench.py does) it averages the
-        # gradients INSIDE every native backward call, the generator's in phases overlapped with the rest of its backward;
-        # not attached it is applied after each backward (bucketed all-reduce of the .grad tensors).
-        self.grad_sync = None
+        # Data parallel (see _DataParallel): attached (what bench.py does) the generator's gradient is averaged INSIDE its one
+        # backward call, in phases overlapped with the rest of that backward; the discriminator's real + fake pass accumulate
+        # and are exchanged once.
 
-    def _sync(self, params):
-        if self.grad_sync is not None and not self.grad_sync.attached:
-            self.grad_sync.allreduce(params)
+    _once = ("netD",)
 
     def optimize_parameters(self, x, y):
         # ---- generator (train.py:330-333)
@@ -85,7 +109,7 @@ class PairedSRGAN:
         self.optimizer_D.step()
 
 
-class StackedSR:
+class StackedSR(_DataParallel):
     """BASELINE.json configs[4] ("Sat2Aerx8 stress"): RDDBNet stages stacked end to end (reference rddb.py:85-114, two instances:
     x4 then x2 by default -- SURVEY.md section 8d restates the configuration), one L1 loss on the final output, one Adam over
     all stages (trainCas.py:38-41 hyper-parameters).  A later stage's input gradient flows into the earlier stage through
@@ -109,8 +133,12 @@ class StackedSR:
         self.optimizer = Adam(itertools.chain(*[n.parameters() for n in self.nets]), lr=lr)
         self.micro_batch = micro_batch
         self.loss_scale = float(loss_scale)
+        self.dynamic_scale = self.loss_scale != 1.0     # fp16: check every step's gradients, back off on overflow, grow back slowly
+        self.growth_interval = 200
+        self._good_steps = 0
         self.skipped_steps = 0
-        self.grad_sync = None
+
+    _once = ("nets",)         # micro-batches: one exchange of the accumulated gradient per optimiser step
 
     def parameters(self):
         return itertools.chain(*[n.parameters() for n in self.nets])
@@ -132,18 +160,24 @@ class StackedSR:
             (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             total = loss.detach() if total is None else total + loss.detach()
             del out, loss
-        if self.grad_sync is not None and not self.grad_sync.attached:
-            self.grad_sync.allreduce(self.parameters())
+        self._sync(self.parameters())
         self.loss = total
-        if self.loss_scale != 1.0:
+        if self.dynamic_scale:
+            # the check does not depend on the CURRENT scale (it may have backed off to 1): an overflowing step must never reach
+            # Adam.  Growth as torch.cuda.amp.GradScaler: x2 after `growth_interval` consecutive finite steps.
             grads = [p.grad for p in self.parameters() if p.grad is not None]
             found_inf = torch.zeros(1, device=grads[0].device)
             inv = torch.full((1,), 1.0 / self.loss_scale, device=grads[0].device)
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv)
             if float(found_inf) != 0.0:          # (one host sync per step, scaled mode only)
                 self.skipped_steps += 1
+                self._good_steps = 0
                 self.loss_scale = max(1.0, self.loss_scale * 0.5)
                 return
+            self._good_steps += 1
+            if self._good_steps >= self.growth_interval:
+                self._good_steps = 0
+                self.loss_scale = min(self.loss_scale * 2.0, 65536.0)
         self.optimizer.step()
 
 
@@ -197,7 +231,7 @@ class CycleParams:
         self.G_A = "RDDBNet"
 
 
-class SRCycleGAN:
+class SRCycleGAN(_DataParallel):
     """Full cycle step of reference src/train.py:145-340.  G_A = RDDBNet (LR->HR), G_B = RDDBNetA (HR->LR,
     build-defined), D_A on HR images, D_B on LR images."""
 
@@ -223,13 +257,10 @@ class SRCycleGAN:
         self.optimizer_D = Adam(itertools.chain(self.netD_A.parameters(), self.netD_B.parameters()),
                                             lr=1e-5, betas=(opt.beta1, 0.999))
         self.optimizers = [self.optimizer_G, self.optimizer_D]
-        self.grad_sync = None
+
+    _once = ("netG_A", "netG_B", "netD_A", "netD_B")     # three passes per generator, two per discriminator and step
 
     set_requires_grad = staticmethod(set_requires_grad)
-
-    def _sync(self, params):
-        if self.grad_sync is not None and not self.grad_sync.attached:
-            self.grad_sync.allreduce(params)
 
     def forward(self, realA, realB):                                     # train.py:228-249 (net == '1')
         self.real_A, self.real_B = realA, realB

@@ -67,6 +67,52 @@ def _worker(rank, world, port, q):
         want = torch.arange(arena.flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
         assert torch.allclose(arena.flat, want), float((arena.flat - want).abs().max())
         assert gs.stats["calls"] == 1 and gs.stats["phases"] == 3 and gs.stats["bytes"] == arena.flat.numel() * 4, gs.stats
+        # 5. a network that runs several times per optimiser step (once()): its backward calls only accumulate, sync() exchanges
+        #    the accumulated gradient ONCE, in place in the arena the .grads alias: bytes on the wire == 1 x parameter bytes
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(s)) for s in [(4, 3), (4,), (2, 2), (5,)]])
+        net2 = Net()
+        ps2 = list(net2.parameters())
+        gs2 = sd.GradSync(bucket_mb=0.00002, phases=3).once(net2)          # 5-float pieces: several collectives per arena
+        gs2._active = True
+        import srcgan_amd.model as smodel
+        assert "rddb" not in smodel._phase_hooks
+        gs2.attach()
+        try:
+            sd.GradSync().attach()
+            raise AssertionError("a second attach must be refused")
+        except RuntimeError:
+            pass
+        nbytes = sum(p.numel() for p in ps2) * 4
+        for call in range(3):                                            # three backward calls of one step
+            ar = _GradArena(ps2, [True] * len(ps2))
+            ar.flat.copy_(torch.arange(ar.flat.numel(), dtype=torch.float32) + 10.0 * call + rank)
+            gs2.phase_done(ar, [p.detach() for p in ps2], types.SimpleNamespace(legacy=0, down=0), 0, 0, 0)      # must not reduce
+            for p, v in zip(ps2, ar.views):                              # what AccumulateGrad does: adopt, then add in place
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    p.grad += v
+        assert gs2.stats["bytes"] == 0 and gs2.stats["collectives"] == 0, gs2.stats
+        gs2.sync(ps2)
+        tot = sum(torch.arange(nbytes // 4, dtype=torch.float32) + 10.0 * c for c in range(3))
+        want2 = tot + 3.0 * (sum(range(world)) / world)
+        got2 = torch.cat([p.grad.reshape(-1) for p in ps2])
+        assert torch.allclose(got2, want2), float((got2 - want2).abs().max())
+        assert gs2.stats["bytes"] == nbytes and gs2.stats["collectives"] > 1 and gs2.stats["calls"] == 1, gs2.stats
+        gs2.sync([p for p in ps2 if False])                                # nothing to do
+        gs2.detach()
+        # ... and the flatten fallback when the gradients are separate allocations
+        gs3 = sd.GradSync(bucket_mb=0.0001)
+        for i, p in enumerate(ps2):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        gs3.sync(ps2)
+        for i, p in enumerate(ps2):
+            assert torch.allclose(p.grad, torch.full_like(p, (sum(range(1, world + 1)) / world) * (i + 1)))
+        info = sd.dist_info()
+        assert info["backend"] == "gloo" and info["world_size"] == world and info["ranks_seen"] == world, info
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))
@@ -96,3 +142,19 @@ def test_world_size_one_is_a_noop():
     p.grad = torch.full((3,), 2.0)
     sync.allreduce([p])
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+    sync.sync([p])
+    assert torch.equal(p.grad, torch.full((3,), 2.0)) and sync.stats["bytes"] == 0
+    assert sd.dist_info() == {"backend": None, "world_size": 1, "ranks_seen": 1, "nccl_version": None}
+
+
+def test_visible_gpu_count_reads_no_runtime(monkeypatch):
+    sys.path.insert(0, ROOT)
+    from srcgan_amd import dist as sd
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert sd.visible_gpu_count() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4")
+    assert sd.visible_gpu_count() == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert sd.visible_gpu_count() >= -1           # sysfs (KFD topology), or -1 where it is not readable: never opens HIP

@@ -72,8 +72,10 @@ def run(sync):
     torch.cuda.synchronize()
     if sync == "attached":
         st = m.grad_sync.stats
-        # per step: one generator backward in 3 phases + two discriminator backward calls with parameter gradients
-        assert st["calls"] == 2 * 3 and st["phases"] == 2 * (3 + 2), st
+        # per step: one generator backward in 3 phases (averaged inside it) + ONE exchange of the discriminator's accumulated
+        # gradient (its real and fake pass only accumulate): every parameter byte crosses the wire exactly once per step
+        nbytes = sum(p.numel() * 4 for p in list(m.netG.parameters()) + list(m.netD.parameters()))
+        assert st["calls"] == 2 * 2 and st["phases"] == 2 * 3 and st["bytes"] == 2 * nbytes, (st, nbytes)
         m.grad_sync.detach()
     return [p.detach().clone() for p in list(m.netG.parameters()) + list(m.netD.parameters())], float(m.loss_G), float(m.loss_D)
 a, b, c = run(False), run(True), run("attached")
@@ -108,15 +110,21 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     assert line["roofline"] is not None and line["cpu_baseline"] is None
 
 
-def test_bench_gpus2_launches_its_own_ranks():
-    """`python bench.py --gpus 2` exactly as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the parent starts two
-    fresh rank processes before touching a GPU, relays rank 0's single JSON line.  One-device rehearsal over gloo."""
+@pytest.mark.parametrize("cfg", ["paired", "cycle", "x8"])
+def test_bench_gpus2_launches_its_own_ranks(cfg):
+    """`python bench.py --gpus 2 [--config ...]` exactly as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the parent
+    starts two fresh rank processes before touching a GPU, relays rank 0's single JSON line.  One-device rehearsal over gloo, for
+    the default configuration and for the two whose networks run several times per step (cycle: three passes per generator; x8:
+    micro-batches) -- the line's `dist` object must show both ranks in the collective and every parameter byte exchanged exactly
+    once per step."""
     env = dict(os.environ)
     env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SRCGAN_FORCE_DIST"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--batch", "2", "--nb", "1", "--lr-size", "64"],
+    extra = {"paired": ["--batch", "2", "--nb", "1", "--lr-size", "64"],
+             "cycle": ["--config", "cycle", "--batch", "2", "--nb", "1", "--lr-size", "32"],
+             "x8": ["--config", "x8", "--batch", "2", "--nb", "1", "--lr-size", "16", "--micro-batch", "1"]}[cfg]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -124,6 +132,65 @@ def test_bench_gpus2_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
     assert line["config"]["parallelism"] == "dp2" and line["cpu_baseline"] is None
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_seen"] == 2, d
+    assert line["config"]["gradient_exchange"].startswith("gloo all-reduce over 2 rank"), line["config"]
+    assert d["grad_sync"]["bytes"] == d["steps_counted"] * d["param_bytes"], d
+
+
+def test_two_rank_cycle_step_exchanges_each_network_once_and_gives_the_mean():
+    """world_size 2 on the one device (gloo), the full cycle harness (three passes per generator, two per discriminator and step):
+    with GradSync attached and the harness's networks registered once(), the gradients in front of each optimizer.step() are the
+    mean of the two ranks' gradients -- which each rank also computes alone, from both seeded batches -- and the bytes exchanged
+    per step are exactly one copy of the parameters."""
+    code = r'''
+import torch, sys, os, itertools
+sys.path.insert(0, %r)
+from srcgan_amd import dist as sdist
+from srcgan_amd.train import SRCycleGAN, CycleParams
+rank, local, world = sdist.init_from_env()
+import torch.distributed as dist
+assert world == 2 and dist.get_backend() == "gloo"
+def batch(r):
+    g = torch.Generator().manual_seed(11 + r)
+    return torch.rand(2, 3, 16, 16, generator=g).cuda(), torch.rand(2, 3, 32, 32, generator=g).cuda()
+opt = CycleParams("cuda"); opt.nf, opt.nb, opt.gc, opt.ndf, opt.n_layers, opt.pool_size, opt.dtype = 16, 2, 8, 16, 2, 0, "fp32"
+torch.manual_seed(0)
+m = SRCycleGAN(opt)
+gen = lambda: list(itertools.chain(m.netG_A.parameters(), m.netG_B.parameters()))
+dis = lambda: list(itertools.chain(m.netD_A.parameters(), m.netD_B.parameters()))
+def grads(batches, sync):
+    for p in gen() + dis(): p.grad = None
+    for a, b in batches:
+        m.forward(a, b)
+        m.set_requires_grad([m.netD_A, m.netD_B], False)
+        m.backward_G()
+    if sync: m._sync(gen())
+    gg = [p.grad.detach().clone() for p in gen()]
+    for a, b in batches:
+        m.forward(a, b)
+        m.set_requires_grad([m.netD_A, m.netD_B], True)
+        m.backward_D_A(); m.backward_D_B()
+    if sync: m._sync(dis())
+    torch.cuda.synchronize()
+    return gg + [p.grad.detach().clone() for p in dis()]
+ref = [g / 2 for g in grads([batch(0), batch(1)], False)]
+gs = sdist.GradSync(bucket_mb=0.05, phases=3).attach()
+m.grad_sync = gs
+got = grads([batch(rank)], True)
+gs.detach()
+worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-20)) for a, b in zip(got, ref))
+assert worst < 1e-5, worst
+nbytes = sum(p.numel() * 4 for p in gen() + dis())
+assert gs.stats["bytes"] == nbytes and gs.stats["phases"] == 0 and gs.stats["calls"] == 2, (gs.stats, nbytes)
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    env = dict(os.environ)
+    env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SRCGAN_FORCE_DIST"):
+        env.pop(k, None)
+    return _run_two_ranks(code, env)
 
 
 def test_two_ranks_attached_sync_gives_the_mean_gradient():
@@ -171,10 +238,15 @@ print("ok")
     env.update(SRCGAN_LOCAL_DEVICE="0", SRCGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SRCGAN_FORCE_DIST"):
         env.pop(k, None)
-    script = os.path.join(ROOT, "gpurun_out", "_dp_mean_test.py")
-    os.makedirs(os.path.dirname(script), exist_ok=True)
-    with open(script, "w") as f:
-        f.write(code)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), script], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    return _run_two_ranks(code, env)
+
+
+def _run_two_ranks(code, env):
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:           # (not a *_test.py under the repo: pytest would try to collect it)
+        script = os.path.join(tmp, "two_rank_script.py")
+        with open(script, "w") as f:
+            f.write(code)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port()), script], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.count("ok") == 2, (out.stdout[-500:], out.stderr[-3000:])

@@ -11,7 +11,7 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 1e-3, "bf16": 2e-2}
+TOL = {"fp32": 1e-3, "bf16": 2e-2, "fp16": 4e-3}       # fp16: 11 significant bits, inputs quantised like the kernel sees them
 
 
 @pytest.fixture(scope="module")
@@ -24,7 +24,7 @@ def ops():
 
 def _q(t, dt):
     """quantise reference inputs like the kernel sees them"""
-    return t.to(torch.bfloat16).float() if dt == "bf16" else t
+    return t.to(torch.bfloat16).float() if dt == "bf16" else t.to(torch.float16).float() if dt == "fp16" else t
 
 
 def _nhwc(ops, t, cs=None, dt="fp32"):
@@ -289,7 +289,7 @@ def test_wgrad_dense_block(ops, dt, nf, gc, hw):
 # Blocked (plane-major) layout of the dense-block buffers + the production kernel variants it selects
 # (loader-specialised 3x3 kernel with resident weights / operand-set specialisations, dense wgrad fast path).
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,hw", [(64, 32, (16, 32)), (128, 32, (33, 70)), (160, 32, (16, 64)), (192, 64, (20, 40))])
 def test_conv3x3_blocked_layout(ops, dt, cin, cout, hw):
     """RDB conv on blocked buffers: forward (bias + LeakyReLU into the block's own slice when it fits, else residual form),
@@ -323,13 +323,16 @@ def test_conv3x3_blocked_layout(ops, dt, cin, cout, hw):
     assert rel_err(ops.to_nchw(y2).cpu(), ref) < TOL[dt]
 
 
-@pytest.mark.parametrize("cin,hw", [(64, (16, 32)), (96, (33, 70)), (160, (16, 64))])
-def test_conv3x3_sign_masks(ops, cin, hw):
-    """LeakyReLU sign masks (one bit per channel, u32 per pixel) of the dense-block convs: the forward conv writes them, the
-    gradient-slice conv reads them instead of the activation -- bit-identical to the mz operand form; misuse is refused."""
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin,hw", [(64, (16, 32)), (96, (33, 70)), (128, (32, 64)), (160, (16, 64))])
+def test_conv3x3_sign_masks(ops, cin, hw, dt):
+    """LeakyReLU sign masks (one bit per channel, u32 per pixel) of the dense-block convs, both 16-bit types: the forward conv writes
+    them, the gradient-slice conv reads them instead of the activation -- bit-identical to the mz operand form; misuse is refused.
+    Covers the three kernel classes of the training step (three stages + resident weights at Cin 64, resident weights up to Cin
+    128, streamed weights above) on whole and ragged tiles."""
     torch.manual_seed(23)
     H, W = hw
-    B, Cc, cout, dt = 2, 192, 32, "bf16"
+    B, Cc, cout = 2, 192, 32
     buf = torch.rand(B, Cc, H, W) - 0.5
     w = torch.randn(cout, cin, 3, 3) * 0.1
     b = torch.randn(cout) * 0.1
@@ -357,13 +360,14 @@ def test_conv3x3_sign_masks(ops, cin, hw):
         ops.conv_igemm(xn, wp, y_m, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), sign_in=sign)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("blocked", [False, True])
 @pytest.mark.parametrize("hw", [(8, 64), (16, 32), (12, 96)])
-def test_wgrad_dense_production_tiles(ops, blocked, hw):
-    """nf=64, gc=32 in bf16 on whole tiles: the 128-row (4x2 waves) and 64-row (2x4 waves) fast-path kernels, first / interior /
-    last tile rows and columns, interleaved and blocked operands."""
+def test_wgrad_dense_production_tiles(ops, blocked, hw, dt):
+    """nf=64, gc=32 in bf16 AND fp16 (BASELINE configs[4] runs the f16 instantiations) on whole tiles: the 128-row (4x2 waves) and
+    64-row (2x4 waves) fast-path kernels, first / interior / last tile rows and columns, interleaved and blocked operands."""
     torch.manual_seed(12)
-    dt, nf, gc = "bf16", 64, 32
+    nf, gc = 64, 32
     H, W = hw
     Cc = nf + 4 * gc
     A = _q(torch.rand(2, Cc, H, W) - 0.5, dt)
