@@ -282,7 +282,7 @@ typedef struct srcgan_net_opts {
     const void* guard;
 } srcgan_net_opts;
 /* 64-bit order-independent fingerprint of a list of f32 tensors (every bit of every element).  table_dev: device int64
- * [ntensors][3] = {pointer, element count, first block}; tensor t is served by the blocks [first block(t), first block(t+1)) of 65536
+ * [ntensors][3] = {pointer, element count, first block}; tensor t is served by the blocks [first block(t), first block(t+1)) of 16384
  * elements each; nblocks = their total.  out_u64: one device word (zeroed and accumulated on `stream`). */
 int srcgan_params_fingerprint(const void* table_dev, int ntensors, long nblocks, void* out_u64, void* stream);
 int srcgan_rddbnet_num_params(const srcgan_rddbnet_cfg* c);

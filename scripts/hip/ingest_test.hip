@@ -298,6 +298,17 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 2 && argv[2][0] == 's') {
+        // round 3: the MFMA shape in the Cout = 64 regime (72 MFMA-equivalents and 42 fragment reads per wave and chunk, DMA running):
+        // 32x32x16 against 16x16x32 (two per 32x32x16: same FLOPs, same LDS bytes), interleaved, 4 rounds
+        for (int rep = 0; rep < 4; ++rep) {
+            run<true,  true,  true,  8, 2, 40, 42, 72>("Cout=64 ratio, 32x32x16", buf, total, sink, 96, span);
+            run<true,  true,  true,  8, 2, 40, 42, 72, 16, 0, 0, 0, 2>("Cout=64 ratio, 16x16x32", buf, total, sink, 96, span);
+            run<false, true,  true,  8, 2, 40, 42, 72>("  no DMA, 32x32x16", buf, total, sink, 96, span);
+            run<false, true,  true,  8, 2, 40, 42, 72, 16, 0, 0, 0, 2>("  no DMA, 16x16x32", buf, total, sink, 96, span);
+        }
+        return 0;
+    }
     if (!all) return 0;
     const int NC = 96;
     printf("-- flat 1-KiB pieces streamed from 1 GiB, generic read/MFMA groups\n");

@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     // ---- per-thread staging descriptors (independent of the channel chunk).  Loads are issued
     // unconditionally from a clamped address and zeroed by a select afterwards: no branches, so the
     // compiler keeps all of a stage's loads in flight together.
+    // (Round 3, measured: for stride 2 the 32 lanes of a pixel-fragment read are 160 bytes apart -- 8 distinct 16-byte slots, a 2-way
+    //  bank conflict, SQ_LDS_BANK_CONFLICT 104 k cycles/us on the 4x4 stride-2 layers.  Keeping the even halo columns of a row in
+    //  front of the odd ones makes those reads consecutive and conflict-free; the layers' time did not move (0.841 -> 0.843 ms per
+    //  discriminator pass, same-box A/B): with 2 chunks x 16 MFMAs between barrier pairs they are bound by the per-tile prologue
+    //  and the barrier chain, not by LDS reads.  Not kept.)
     int h_goff[HIT];                  // byte offset of this thread's halo piece in image b (chunk 0), -1 = outside
     const int part = tid & 3;
 #pragma unroll

@@ -374,21 +374,38 @@ int sg_fill_zero_guarded(void* p, size_t bytes, const unsigned long long* guard,
 
 // 64-bit fingerprint of a parameter list: sum over tensors t and elements i of mix(bits(x[t][i]), i, t).  The sum is order independent
 // (atomic adds commute), every bit of every element takes part, and a changed element changes the sum unless 2^-64 luck intervenes.
-__device__ __forceinline__ unsigned long long sg_mix64(unsigned long long z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// Two independent 32-bit avalanche mixes (murmur3's finaliser on differently keyed words) make the two halves; 64-bit multiplies
+// would cost ~16 VALU each.  A block serves a 16 Ki-element slice with 8 loads in flight per thread: the first version (one
+// dependent load per iteration, 64 Ki-element slices) was latency-bound at 120 us per call for 66 MB -- 1 ms of a 138 ms step.
+__device__ __forceinline__ unsigned sg_fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
 }
+#define SG_FP_SLICE 16384
 __global__ __launch_bounds__(256) void params_fingerprint_k(const long* __restrict__ table, int ntens, unsigned long long* __restrict__ out) {
-    // block -> (tensor, 64 Ki-element slice of it): binary search over the table's cumulative block counts (third column)
+    // block -> (tensor, slice): binary search over the table's cumulative block counts (third column)
     int lo = 0, hi = ntens - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[3 * mid + 2] <= (long)blockIdx.x) lo = mid; else hi = mid - 1; }
-    const unsigned* p = (const unsigned*)table[3 * lo];
-    const long n = table[3 * lo + 1], i0 = ((long)blockIdx.x - table[3 * lo + 2]) * 65536;
-    const long i1 = i0 + 65536 < n ? i0 + 65536 : n;
-    const unsigned long long salt = sg_mix64(0x9E3779B97F4A7C15ull * (unsigned long long)(lo + 1));
-    unsigned long long h = 0;
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) h += sg_mix64((((unsigned long long)i << 32) | p[i]) ^ salt);
+    const unsigned* __restrict__ p = (const unsigned*)table[3 * lo];
+    const long n = table[3 * lo + 1], i0 = ((long)blockIdx.x - table[3 * lo + 2]) * SG_FP_SLICE;
+    const long i1 = i0 + SG_FP_SLICE < n ? i0 + SG_FP_SLICE : n;
+    const unsigned salt_a = sg_fmix32(0x9E3779B9u * (unsigned)(lo + 1)), salt_b = sg_fmix32(0x7F4A7C15u + (unsigned)lo);
+    unsigned long long ha = 0, hb = 0;
+    for (long base = i0 + threadIdx.x; base < i1; base += 256 * 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const long i = base + k * 256; v[k] = i < i1 ? p[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long i = base + k * 256;
+            if (i < i1) {
+                const unsigned iu = (unsigned)i;
+                ha += sg_fmix32((v[k] ^ salt_a) + iu * 0x9E3779B1u);
+                hb += sg_fmix32((v[k] + salt_b) ^ (iu * 0x85EBCA77u + 0x165667B1u));
+            }
+        }
+    }
+    unsigned long long h = (hb << 32) + ha + (hb >> 32);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
     __shared__ unsigned long long part[4];

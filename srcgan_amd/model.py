@@ -117,7 +117,7 @@ class _PackState:
             rows, blk = [], 0
             for ptr, n in key:
                 rows.append((ptr, n, blk))
-                blk += (n + 65535) // 65536
+                blk += (n + 16383) // 16384              # srcgan_params_fingerprint: 16 Ki-element slices
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_key, self.nblocks = key, blk
             self.valid = [False, False]

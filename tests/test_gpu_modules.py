@@ -419,6 +419,11 @@ def test_resdeconv_bf16_vs_oracle():
           "median native-vs-f32", sorted(r[1] for r in rows)[len(rows) // 2])
     for k, e_f32, fmt, e_emu in rows:
         assert e_f32 < bound(fmt), (k, e_f32, fmt)
+        # native vs the bf16-storage emulation: within 5 % wherever the format itself is accurate; where the format error is large the
+        # two 16-bit evaluations DECORRELATE (measured: layer1.0.bn1.bias native-vs-f32 0.54, emulation-vs-f32 0.50, native-vs-emulation
+        # 0.36) -- bounded by the emulation's own distance from the f32 oracle.  That these errors do not move training is what
+        # tests/test_gpu_trajectory.py::test_cascade_const_lab_trajectories_agree_across_dtypes measures (colouriser loss curve 0.5 % from fp32).
+        assert e_emu < max(5e-2, fmt + 5e-3), (k, e_emu, fmt)
         if k.startswith(("pred", "deconv13", "upRes3.1")):
             assert e_f32 < 5e-2, k
 
