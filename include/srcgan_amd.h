@@ -106,6 +106,12 @@ typedef struct srcgan_conv_desc {
      *   sign_in : read instead of mz:  v *= bit ? 1 : mslope
      * A descriptor that sets either and does not meet the conditions is refused (no silent fallback). */
     void* sign_out; const void* sign_in;
+    /* npar == 4: the input gradient of a 4x4 stride-2 pad-1 convolution (model/model.py:612-634) with all four output parities in
+     * ONE launch.  x = dy [B,H,W,Cin = the layer's Cout], y = dx [B,YH,YW,..] (Cout = the layer's Cin), kh = kw = 2, stride = 1:
+     *   dx[2t+a][2u+b] = sum_{ty,tx in {0,1}} dy[t+a-1+ty][u+b-1+tx] * pack_q[tap (ty,tx)],   q = 2a + b,
+     * pack_q = wp + q * wpar_stride bytes (rows = the layer's Cin, k = its Cout, taps ky = (a?2:3) - 2ty, kx = (b?2:3) - 2tx).
+     * OH / OW / pad / os / oa / ob are derived from YH, YW; epilogue operands (mz, r1, ...) are indexed like y.  npar == 0: plain. */
+    int npar; long wpar_stride;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);
 

@@ -56,7 +56,7 @@ class ConvDesc(C.Structure):
                 ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("slope", C.c_float), ("mslope", C.c_float),
                 ("act", C.c_int),
                 ("x_plane", C.c_long), ("y_plane", C.c_long), ("r1_plane", C.c_long), ("r2_plane", C.c_long), ("mz_plane", C.c_long), ("rev_batch", C.c_int),
-                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p)]
+                ("sign_out", C.c_void_p), ("sign_in", C.c_void_p), ("npar", C.c_int), ("wpar_stride", C.c_long)]
 
 
 class WgradDesc(C.Structure):

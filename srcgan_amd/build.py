@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcgan_amd.so")
-SOURCES = ["conv_igemm.hip", "conv3x3_dma.hip", "conv_wgrad.hip", "wgrad_dense.hip", "elementwise.hip", "groupnorm.hip", "metrics.hip", "colour.hip", "nets.hip"]
+SOURCES = ["conv_igemm.hip", "conv_par4.hip", "conv3x3_dma.hip", "conv_wgrad.hip", "wgrad_dense.hip", "elementwise.hip", "groupnorm.hip", "metrics.hip", "colour.hip", "nets.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

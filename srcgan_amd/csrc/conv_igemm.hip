@@ -349,6 +349,7 @@ static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hip
 }
 
 int sg_conv3x3_dma(const ConvP& p, int dtype, hipStream_t st);      // conv3x3_dma.hip
+int sg_dgrad_s2k4(const ConvP& p, int dtype, hipStream_t st);       // conv_par4.hip
 static const bool g_force_generic = sg_env("SRCGAN_GENERIC_3X3") != nullptr;   // A/B switch for benchmarking
 
 extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
@@ -403,6 +404,13 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d->npar) {
+        SG_REQUIRE(d->npar == 4 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 && !d->x_plane && !d->y_plane &&
+                   !d->sign_in && !d->sign_out && !d->bias,
+                   "srcgan_conv_igemm: npar must be 0 or 4 (2x2 stride-1 parity packs wpar_stride bytes apart, interleaved tensors, no bias / sign masks)");
+        p.wpar = d->wpar_stride;
+        return sg_dgrad_s2k4(p, d->dtype, st);
+    }
     if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane)) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
     if (d->Cout <= 32) {
@@ -412,7 +420,7 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     }
 #ifdef SG_MT4_22
     // (variant) stride-2 parity gradients with >= 128 output rows: one 128-row tile per workgroup halves the dy staging per FLOP
-    if (sg_is16(d->dtype) && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)
+    if (d->dtype == SRCGAN_BF16 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)       // (the variant instantiates bf16 only)
         return launch_igemm<__bf16, 2, 2, 1, 4, SG_PT22, false>(p, d->Cout / 128, st);
 #endif
     const int ctiles = cdiv(d->Cout, 64);

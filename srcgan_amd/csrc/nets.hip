@@ -975,6 +975,18 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
             if (mz.p) cv.mask(mz, 0);
             SG_TRY(cv.run(st));
         } else {
+            // stride-2 layers: all four output parities of the input gradient from one staged dy tile (conv_par4.hip); the four
+            // parity packs are equally spaced.  (SRCGAN_NO_PAR4, diagnostic builds: the four separate 2x2 launches of rounds 1-2.)
+            static const bool no_par4 = sg_env("SRCGAN_NO_PAR4") != nullptr;
+            const long wstep = (long)(P.wd[l][1] - P.wd[l][0]);
+            const bool even = P.wd[l][2] - P.wd[l][1] == (size_t)wstep && P.wd[l][3] - P.wd[l][2] == (size_t)wstep;
+            if (!no_par4 && even && ih >= 2 && iw >= 2 && cin % (16 / P.esz) == 0 && dst.cs % (16 / P.esz) == 0) {
+                Conv cv(dt, 2, 2, 1);
+                cv.in(dcur, B, oh, ow, dcur_c).w(wp + P.wd[l][0]).out(dst, (ih + 1) / 2, (iw + 1) / 2, cin).scatter(2, 0, 0, ih, iw);
+                cv.d.npar = 4; cv.d.wpar_stride = wstep;
+                if (mz.p) cv.mask(mz, 0);
+                SG_TRY(cv.run(st));
+            } else
             for (int q = 0; q < 4; ++q) {
                 const int a = q >> 1, bb = q & 1;
                 const int mh = (ih - a + 1) / 2, mw = (iw - bb + 1) / 2;

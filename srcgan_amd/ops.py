@@ -83,7 +83,7 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
                mz: Optional[torch.Tensor] = None, mz_coff: int = 0, mz_c0: int = 0, mslope: float = 0.2,
                os: int = 1, oa: int = 0, ob: int = 0, x_plane: int = 0, y_plane: int = 0, r1_plane: int = 0, r2_plane: int = 0,
                mz_plane: int = 0, shape: Optional[Tuple[int, int, int]] = None, sign_out: Optional[torch.Tensor] = None,
-               sign_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+               sign_in: Optional[torch.Tensor] = None, npar: int = 0, wpar_stride: int = 0) -> torch.Tensor:
     """x, y, r1, r2, mz: NHWC tensors [B,H,W,cs] of the compute dtype.  Writes into y (returned).
     Blocked-layout tensors ([planes,B,H,W,KCE], see make_blocked) pass *_plane = plane stride in bytes and shape=(B,H,W).
     sign_out / sign_in: int32 [B,OH,OW] LeakyReLU sign masks (bit c = channel c), see srcgan_conv_desc in include/srcgan_amd.h."""
@@ -114,6 +114,7 @@ def conv_igemm(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, *, kh: int, k
         d.sign_out = sign_out.data_ptr()
     if sign_in is not None:
         d.sign_in = sign_in.data_ptr()
+    d.npar, d.wpar_stride = npar, wpar_stride        # npar = 4: all four parities of a 4x4 stride-2 input gradient (see the header)
     d.alpha, d.slope, d.mslope, d.act = alpha, slope, mslope, int(act)
     d.x_plane, d.y_plane, d.r1_plane, d.r2_plane, d.mz_plane = x_plane, y_plane, r1_plane, r2_plane, mz_plane
     N.check(N.lib().srcgan_conv_igemm(C.byref(d), N.stream_ptr(x.device)), "srcgan_conv_igemm")

@@ -481,3 +481,44 @@ def test_space_to_depth_forms(ops, dt, shape):
     assert torch.equal(g, refg)
     with pytest.raises(RuntimeError):
         N.check(N.lib().srcgan_nchw_f32_to_s2d(x.data_ptr(), s2d.data_ptr(), B, Cc, H + 1, W, N.dtype_id(tdt), st), "odd")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,hw,mask", [(64, 128, (16, 64), True), (128, 256, (33, 70), True), (32, 64, (7, 34), False), (64, 32, (20, 22), True)])
+def test_stride2_input_gradient_all_parities_in_one_launch(ops, dt, cin, cout, hw, mask):
+    """Input gradient of a 4x4 stride-2 pad-1 convolution (PatchGAN layers, model.py:612-634): the fused four-parity kernel
+    (conv_par4.hip, descriptor npar = 4) against (a) the four separate 2x2 stride-1 parity launches it replaces -- same summation
+    order per accumulator, so bit for bit -- and (b) torch's conv_transpose2d on the quantised operands, with the LeakyReLU' mask
+    operand; even and odd gradient extents (ragged parities), whole and ragged tiles."""
+    torch.manual_seed(41)
+    H, W = hw                                    # extent of dx (the layer's input); dy is (H + 2 - 4) // 2 + 1
+    oh, ow = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    B = 2
+    w = torch.randn(cout, cin, 4, 4) * 0.05
+    dy = torch.rand(B, cout, oh, ow) - 0.5
+    z = torch.rand(B, cin, H, W) - 0.5
+    wc = w.cuda()
+    esz = 4 if dt == "fp32" else 2
+    packs = [ops.pack_weight(wc, cin, cout, 2, 2, 16, cin * 16, -8, -2, (2 if a else 3) * 4 + (2 if b else 3), dt) for a in (0, 1) for b in (0, 1)]
+    wall = torch.cat([pk.reshape(-1).view(torch.uint8) for pk in packs])
+    stride = packs[0].numel() * packs[0].element_size()
+    assert stride % 256 == 0
+    dyd, zd = _nhwc(ops, dy, cout, dt), _nhwc(ops, z, cin, dt)
+    fused = torch.full((B, H, W, cin), 7.0, device="cuda", dtype=dyd.dtype)
+    ops.conv_igemm(dyd, wall, fused, kh=2, kw=2, Cout=cin, OH=(H + 1) // 2, OW=(W + 1) // 2, os=2, npar=4, wpar_stride=stride,
+                   **(dict(mz=zd, mz_coff=0, mz_c0=0) if mask else {}))
+    sep = torch.full((B, H, W, cin), 7.0, device="cuda", dtype=dyd.dtype)
+    for a in (0, 1):
+        for b in (0, 1):
+            mh, mw = (H - a + 1) // 2, (W - b + 1) // 2
+            ops.conv_igemm(dyd, packs[a * 2 + b], sep, kh=2, kw=2, Cout=cin, OH=mh, OW=mw, pad=(0 if a else 1, 0 if b else 1), os=2, oa=a, ob=b,
+                           **(dict(mz=zd, mz_coff=0, mz_c0=0) if mask else {}))
+    assert torch.equal(fused, sep)
+    ref = F.conv_transpose2d(_q(dy, dt), _q(w, dt), None, 2, 1, output_padding=(H - ((oh - 1) * 2 + 2), W - ((ow - 1) * 2 + 2)))
+    if mask:
+        zq = _q(z, dt)
+        ref = ref * torch.where(zq > 0, torch.ones_like(zq), torch.full_like(zq, 0.2))
+    assert rel_err(ops.to_nchw(fused).cpu(), ref) < TOL[dt]
+    with pytest.raises(RuntimeError):            # odd channel count: refused, the caller keeps the four launches
+        ops.conv_igemm(dyd, wall, torch.zeros(B, H, W, 3, device="cuda", dtype=dyd.dtype), kh=2, kw=2, Cout=3, OH=(H + 1) // 2, OW=(W + 1) // 2, os=2,
+                       npar=4, wpar_stride=stride)
