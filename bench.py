@@ -180,7 +180,7 @@ def _ints(text):
     return [int(t) for t in re.findall(r"(?<![\w.])\d+(?![\w.])", text)]
 
 
-def pmc_traffic(cls):
+def pmc_traffic(cls, config="paired"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, separate --pmc runs of this same command: scripts/profile_round.sh).  PMC counters
     cannot be read from inside the timed process, so this is the last profiled value or null.
@@ -188,7 +188,10 @@ def pmc_traffic(cls):
     ("void wgrad_dense_fast_k<4, 2, 4>(WdP)" or a mangled "_Z..Li4ELi2E..") goes by kernel base name and the leading
     integer template arguments."""
     import glob, re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    # the profile of THIS configuration, latest round (scripts/profile_round.sh <round> [config])
+    pat = re.compile(r"r\d+" + ("" if config == "paired" else "_" + re.escape(config)) + r"_hbm_traffic\.json$")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")) if pat.search(os.path.basename(f)))
+    pmc_traffic.source, pmc_traffic.avg_us = None, None
     if not files:
         return None
     try:
@@ -210,6 +213,7 @@ def pmc_traffic(cls):
             a = re.search(r"<(.*)>\(", name)
             have = _ints(a.group(1)) if a else []
         if have[:len(want)] == want or (want and not have):
+            pmc_traffic.avg_us = v.get("avg_us")          # the kernel's duration in that profile: compare with the live avg_ms (a stale profile shows)
             return v["hbm_bytes_per_launch"]
     return None
 
@@ -420,9 +424,10 @@ def main():
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             roofline = {"bound": "mfma", "kernel": k["cls"], "launches": k["count"], "avg_ms": k["ms"] / k["count"],
                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                        "traffic": pmc_traffic(k["cls"]) if args.config == "paired" else None,
+                        "traffic": pmc_traffic(k["cls"], args.config),
                         "traffic_source": (getattr(pmc_traffic, "source", None) or "none") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                           "command, scripts/profile_round.sh; counters cannot be read inside the timed process)",
+                        "traffic_profile_avg_ms": (pmc_traffic.avg_us / 1e3) if getattr(pmc_traffic, "avg_us", None) else None,
                         "algorithmic_bytes_per_launch": k["bytes"] / k["count"],
                         "algorithmic_gbytes_per_s": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
     barrier()

@@ -430,10 +430,17 @@ def psnr(a: Tensor, b: Tensor) -> Tensor:
     return 10.0 * torch.log10(1.0 / mse_loss(a, b))
 
 
-def gan_loss(pred: Tensor, target_is_real: bool, real_label: float = 1.0, fake_label: float = 0.0) -> Tensor:
-    """GANLoss('lsgan').__call__, train.py:98-127: MSE against an expanded scalar label."""
+def gan_loss(pred: Tensor, target_is_real: bool, real_label: float = 1.0, fake_label: float = 0.0, gan_mode: str = "lsgan") -> Tensor:
+    """GANLoss(gan_mode).__call__, train.py:84-127: 'lsgan' = MSE against an expanded scalar label (:86-87, the mode train.py:186
+    builds); 'vanilla' = BCEWithLogitsLoss against it (:88-89); 'wgangp' = -mean for real, +mean for fake (:121-126)."""
     t = real_label if target_is_real else fake_label
-    return ((pred - t) ** 2).mean()
+    if gan_mode == "lsgan":
+        return ((pred - t) ** 2).mean()
+    if gan_mode == "vanilla":
+        return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, t))
+    if gan_mode == "wgangp":
+        return -pred.mean() if target_is_real else pred.mean()
+    raise NotImplementedError("gan mode %s not implemented" % gan_mode)
 
 
 # ---------------------------------------------------------------------------

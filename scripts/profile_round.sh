@@ -5,17 +5,23 @@
 #   3. HBM traffic of the same command: FETCH_SIZE and WRITE_SIZE in two separate --pmc passes
 #      (MI355X_MICROARCH.md: they do not fit one pass; no trace domains combined with --pmc)
 # The summaries are condensed into profiles/ by scripts/summarize_profile.py (run in the container).
+#   scripts/profile_round.sh r03            the headline configuration -> <R>_kernel_stats.txt, <R>_hbm_traffic.json
+#   scripts/profile_round.sh r03 cycle      another bench configuration -> <R>_cycle_kernel_stats.txt, <R>_cycle_hbm_traffic.json (bench.py
+#                                           reads the traffic file of ITS configuration: roofline.traffic is then not null for it either)
 set -e
 R=${1:-r01}
+CFG=${2:-paired}
+ARGS=""
+if [ "$CFG" != "paired" ]; then ARGS="--config $CFG --steps 3 --warmup 1"; R=${R}_$CFG; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 900 python bench.py > $OUT/bench_$R.json 2> $OUT/bench_$R.err
+timeout -k 10 900 python bench.py $ARGS > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$R -- python $ROOT/bench.py --no-cpu-baseline > $OUT/prof_$R.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile --steps 2 --warmup 1 > $OUT/pmc_fetch_$R.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile --steps 2 --warmup 1 > $OUT/pmc_write_$R.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$R -- python $ROOT/bench.py --no-cpu-baseline $ARGS > $OUT/prof_$R.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile $ARGS --steps 2 --warmup 1 > $OUT/pmc_fetch_$R.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile $ARGS --steps 2 --warmup 1 > $OUT/pmc_write_$R.log 2>&1
 # keep only the small per-kernel aggregates (the raw traces exceed the 64 MiB merge cap)
 cd $ROOT
 python scripts/summarize_profile.py $R

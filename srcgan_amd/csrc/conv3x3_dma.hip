@@ -630,6 +630,7 @@ static int launch_ls_dir(const ConvP& p, int ctiles, hipStream_t st) {
     { static const char* e = sg_env("SRCGAN_DBG"); q.dbg = e ? atoi(e) : 0; }
     const size_t nunits = (size_t)q.tiles_x * q.tiles_y * p.B * ctiles;
     size_t nwg = (size_t)ncu; if (nwg > nunits) nwg = nunits;
+    if (const char* e = sg_env("SRCGAN_CONV_CUS")) { const int v = atoi(e); if (v > 0 && (size_t)v < nwg) nwg = (size_t)v; }     // diagnostic builds: share the chip with a concurrent kernel
     char cls[96];
     snprintf(cls, sizeof(cls), "conv3x3_ls<%s,MT%d,W%d+%d%s%s,e%d%s>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), MT, 16 / PT, NLW, WRES ? ",wres" : "", NSTG == 3 ? ",s3" : "", EM,
              DIR == 2 ? ",d16" : DIR == 1 ? ",d8" : DIR == 0 ? ",gen" : "");

@@ -750,6 +750,24 @@ extern "C" int srcgan_add_inplace(void* y, int y_cs, int y_coff, const void* x, 
 #define LOSS_BLOCKS 1024
 extern "C" int srcgan_loss_scratch_floats(void) { return LOSS_BLOCKS; }
 
+// KIND: 0 |a - b| (L1), 1 (a - b)^2 (MSE), 2 (a - label)^2 (lsgan: MSE against the expanded scalar label, train.py:86-87),
+//       3 BCE-with-logits against the scalar label (GANLoss 'vanilla', train.py:88-89: max(x,0) - x t + log1p(exp(-|x|)), torch's
+//         stable form), 4 label * a (GANLoss 'wgangp', train.py:121-126: -mean for real, +mean for fake; label = -1 / +1)
+template <int KIND>
+__device__ __forceinline__ float loss_elem(float x, float t) {
+    if (KIND == 0) return fabsf(x - t);
+    if (KIND == 3) return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    if (KIND == 4) return x * t;
+    const float d = x - t;
+    return d * d;
+}
+template <int KIND>
+__device__ __forceinline__ float loss_grad(float x, float t) {       // d elem / d x
+    if (KIND == 0) { const float d = x - t; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    if (KIND == 3) return 1.f / (1.f + expf(-x)) - t;
+    if (KIND == 4) return t;
+    return 2.f * (x - t);
+}
 template <int KIND>
 __global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ a, const float* __restrict__ b, float label,
                                                   long n, float* __restrict__ partial) {
@@ -759,14 +777,13 @@ __global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ a, c
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
         const f32x4 av = *(const f32x4*)(a + e * 4);
         f32x4 bv = {label, label, label, label};
-        if (KIND != 2) bv = *(const f32x4*)(b + e * 4);
+        if (KIND < 2) bv = *(const f32x4*)(b + e * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float d = av[i] - bv[i]; s += (KIND == 0) ? fabsf(d) : d * d; }
+        for (int i = 0; i < 4; ++i) s += loss_elem<KIND>(av[i], bv[i]);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // tail
         const long e = n4 * 4 + threadIdx.x;
-        const float d = a[e] - (KIND == 2 ? label : b[e]);
-        s += (KIND == 0) ? fabsf(d) : d * d;
+        s += loss_elem<KIND>(a[e], KIND >= 2 ? label : b[e]);
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -785,14 +802,16 @@ __global__ __launch_bounds__(256) void loss_final_k(const float* __restrict__ pa
 }
 
 extern "C" int srcgan_loss_fwd(int kind, const float* a, const float* b, float label, long n, float* out, float* scratch, void* stream) {
-    SG_REQUIRE(a && out && scratch && n > 0 && kind >= 0 && kind <= 2, "srcgan_loss_fwd: bad arguments");
-    SG_REQUIRE(kind == 2 || b, "srcgan_loss_fwd: kind %d needs b", kind);
-    SG_REQUIRE(((uintptr_t)a % 16) == 0 && (kind == 2 || ((uintptr_t)b % 16) == 0), "srcgan_loss_fwd: inputs must be 16-byte aligned");
+    SG_REQUIRE(a && out && scratch && n > 0 && kind >= 0 && kind <= 4, "srcgan_loss_fwd: bad arguments");
+    SG_REQUIRE(kind >= 2 || b, "srcgan_loss_fwd: kind %d needs b", kind);
+    SG_REQUIRE(((uintptr_t)a % 16) == 0 && (kind >= 2 || ((uintptr_t)b % 16) == 0), "srcgan_loss_fwd: inputs must be 16-byte aligned");
     long nb = cdivl(n / 4 + 1, 256); if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
     if (kind == 0) hipLaunchKernelGGL(loss_fwd_k<0>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
     else if (kind == 1) hipLaunchKernelGGL(loss_fwd_k<1>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
-    else hipLaunchKernelGGL(loss_fwd_k<2>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    else if (kind == 2) hipLaunchKernelGGL(loss_fwd_k<2>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    else if (kind == 3) hipLaunchKernelGGL(loss_fwd_k<3>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
+    else hipLaunchKernelGGL(loss_fwd_k<4>, dim3((int)nb), dim3(256), 0, st, a, b, label, n, scratch);
     SG_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(256), 0, st, scratch, (int)nb, (float)(1.0 / (double)n), out);
     SG_LAUNCH_CHECK();
@@ -803,22 +822,21 @@ template <int KIND>
 __global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ a, const float* __restrict__ b, float label, long n,
                                                   const float* __restrict__ gout, float gscale, float* __restrict__ da) {
     const float g = gout[0] * gscale;     // upstream gradient * 1/n
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-        const float d = a[e] - (KIND == 2 ? label : b[e]);
-        if (KIND == 0) da[e] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
-        else da[e] = 2.f * d * g;
-    }
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        da[e] = loss_grad<KIND>(a[e], KIND >= 2 ? label : b[e]) * g;
 }
 
 extern "C" int srcgan_loss_bwd(int kind, const float* a, const float* b, float label, long n, const float* gout,
                                float gscale, float* da, void* stream) {
-    SG_REQUIRE(a && gout && da && n > 0 && kind >= 0 && kind <= 2, "srcgan_loss_bwd: bad arguments");
-    SG_REQUIRE(kind == 2 || b, "srcgan_loss_bwd: kind %d needs b", kind);
+    SG_REQUIRE(a && gout && da && n > 0 && kind >= 0 && kind <= 4, "srcgan_loss_bwd: bad arguments");
+    SG_REQUIRE(kind >= 2 || b, "srcgan_loss_bwd: kind %d needs b", kind);
     hipStream_t st = (hipStream_t)stream;
     const float gs = gscale / (float)n;
     if (kind == 0) hipLaunchKernelGGL(loss_bwd_k<0>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
     else if (kind == 1) hipLaunchKernelGGL(loss_bwd_k<1>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
-    else hipLaunchKernelGGL(loss_bwd_k<2>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    else if (kind == 2) hipLaunchKernelGGL(loss_bwd_k<2>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    else if (kind == 3) hipLaunchKernelGGL(loss_bwd_k<3>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
+    else hipLaunchKernelGGL(loss_bwd_k<4>, dim3(ew_blocks(n)), dim3(256), 0, st, a, b, label, n, gout, gs, da);
     SG_LAUNCH_CHECK();
     return 0;
 }

@@ -11,6 +11,7 @@
 // (rows of a tile may belong to different convolutions with different Cin; surplus columns are dropped).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 struct WdSeg { int g0, g1; float* grad; float* bias; int Cin; float alpha; };
 struct WdP {
@@ -674,7 +675,9 @@ static int wd_nsplit(int mt, int nt, int ncit, int dtype, int B, int H, int W) {
     int per_cu = (int)((160 * 1024) / lds); if (per_cu < 1) per_cu = 1;
     if (per_cu * mt * nt > 16) per_cu = 16 / (mt * nt) > 0 ? 16 / (mt * nt) : 1;      // <= 16 waves per CU
     const long ntiles = (long)B * cdiv(H, th) * cdiv(W, 32);
-    long ns = (256L * per_cu) / ncit;
+    long cus = 256;
+    if (const char* e = sg_env("SRCGAN_WD_CUS")) { const int v = atoi(e); if (v > 0 && v < 256) cus = v; }     // diagnostic builds: share the chip with a concurrent kernel
+    long ns = (cus * per_cu) / ncit;
     if (ns > ntiles) ns = ntiles;
     return (int)(ns < 1 ? 1 : ns);
 }

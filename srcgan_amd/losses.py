@@ -16,7 +16,7 @@ from . import _native as N
 
 __all__ = ["L1Loss", "MSELoss", "PSNRLoss", "GANLoss"]
 
-_K_L1, _K_MSE, _K_LABEL = 0, 1, 2
+_K_L1, _K_MSE, _K_LABEL, _K_BCE, _K_SIGNED = 0, 1, 2, 3, 4       # srcgan_loss_fwd kinds; >= 2: scalar label instead of a target tensor
 
 
 def _as_f32(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -30,7 +30,7 @@ class _MeanLossFn(torch.autograd.Function):
         lib = N.lib()
         a32 = _as_f32(a, "loss input")
         b32 = None
-        if kind != _K_LABEL:
+        if kind < _K_LABEL:
             if b.shape != a.shape:
                 raise ValueError(f"loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
             b32 = _as_f32(b, "loss target")
@@ -46,7 +46,7 @@ class _MeanLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         lib = N.lib()
         a32, b32 = ctx.saved_tensors
-        has_b = ctx.kind != _K_LABEL
+        has_b = ctx.kind < _K_LABEL
         gout = gout.contiguous().float()
         da = db = None
         st = N.stream_ptr(a32.device)
@@ -96,8 +96,12 @@ class PSNRLoss(nn.Module):
 
 
 class GANLoss(nn.Module):
-    """GAN objective with the reference's interface (train.py:73-127).  'lsgan' = MSE against the scalar
-    label; the label is folded into the kernel as an immediate instead of ``expand_as``."""
+    """GAN objective with the reference's interface (train.py:67-128): 'lsgan' = MSE against the scalar label (the only mode a
+    reference script constructs, train.py:186), 'vanilla' = BCE-with-logits against it, 'wgangp' = -mean(prediction) for real,
+    +mean for fake.  The label is folded into the reduction kernel as an immediate instead of ``expand_as``.  'DSSIM' (the
+    reference wires ``losses.DSSIMLoss`` there) is outside the native path and refused."""
+
+    _KINDS = {"lsgan": _K_LABEL, "vanilla": _K_BCE, "wgangp": _K_SIGNED}
 
     def __init__(self, gan_mode, device=None, target_real_label=1.0, target_fake_label=0.0):
         super().__init__()
@@ -105,13 +109,16 @@ class GANLoss(nn.Module):
         self.register_buffer("fake_label", torch.tensor(target_fake_label, device=device))
         self._real, self._fake = float(target_real_label), float(target_fake_label)
         self.gan_mode = gan_mode
-        if gan_mode != "lsgan":
-            if gan_mode in ("vanilla", "wgangp", "DSSIM"):
-                raise NotImplementedError(f"gan mode {gan_mode} is outside the native hot path (the reference only builds 'lsgan', train.py:186)")
+        if gan_mode not in self._KINDS:
+            if gan_mode == "DSSIM":
+                raise NotImplementedError("gan mode DSSIM is outside the native hot path (no reference script selects it)")
             raise NotImplementedError("gan mode %s not implemented" % gan_mode)
 
     def get_target_tensor(self, prediction, target_is_real):
         return (self.real_label if target_is_real else self.fake_label).expand_as(prediction)
 
     def forward(self, prediction, target_is_real):
-        return _MeanLossFn.apply(_K_LABEL, self._real if target_is_real else self._fake, prediction, None)
+        kind = self._KINDS[self.gan_mode]
+        if kind == _K_SIGNED:
+            return _MeanLossFn.apply(kind, -1.0 if target_is_real else 1.0, prediction, None)
+        return _MeanLossFn.apply(kind, self._real if target_is_real else self._fake, prediction, None)

@@ -90,6 +90,16 @@ def test_ganloss_modes():
     assert g.get_target_tensor(torch.zeros(2, 1, 3, 3), True).shape == (2, 1, 3, 3)
     with pytest.raises(NotImplementedError):
         srcgan_amd.GANLoss("hinge")
+    for mode in ("vanilla", "wgangp"):                      # the other objectives of train.py:88-95 are native too (round 3)
+        assert srcgan_amd.GANLoss(mode, device="cpu").gan_mode == mode
+    with pytest.raises(NotImplementedError):
+        srcgan_amd.GANLoss("DSSIM")
+    # the oracle's restatement of the three objectives against the torch modules the reference's class wraps (train.py:86-95)
+    x = torch.randn(2, 1, 5, 7) * 4
+    assert torch.allclose(oracle.gan_loss(x, True, gan_mode="vanilla"), torch.nn.BCEWithLogitsLoss()(x, torch.tensor(1.0).expand_as(x)))
+    assert torch.allclose(oracle.gan_loss(x, False, gan_mode="vanilla"), torch.nn.BCEWithLogitsLoss()(x, torch.tensor(0.0).expand_as(x)))
+    assert torch.allclose(oracle.gan_loss(x, True, gan_mode="wgangp"), -x.mean()) and torch.allclose(oracle.gan_loss(x, False, gan_mode="wgangp"), x.mean())
+    assert torch.allclose(oracle.gan_loss(x, False, gan_mode="lsgan"), torch.nn.MSELoss()(x, torch.tensor(0.0).expand_as(x)))
 
 
 def test_unsupported_norm_layer_is_rejected():
