@@ -12,15 +12,23 @@ set -e
 R=${1:-r01}
 CFG=${2:-paired}
 ARGS=""
-if [ "$CFG" != "paired" ]; then ARGS="--config $CFG --steps 3 --warmup 1"; R=${R}_$CFG; fi
+BASE=""
+if [ "$CFG" != "paired" ]; then ARGS="--config $CFG --steps 3 --warmup 1"; BASE="--no-cpu-baseline"; R=${R}_$CFG; fi    # (the CPU leg of the big configurations runs for minutes: scripts/bench_configs.sh has it)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 900 python bench.py $ARGS > $OUT/bench_$R.json 2> $OUT/bench_$R.err
+# heartbeat: the counter passes of the big configurations write nothing for minutes (a silent GPU command is taken to be hung)
+( while true; do sleep 60; echo "[profile_round] $R: still running $(date +%T)"; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
+echo "[profile_round] $R: bench"; timeout -k 10 900 python bench.py $ARGS $BASE > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 cd /tmp && export TMPDIR=/tmp
+echo "[profile_round] $R: kernel trace"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$R -- python $ROOT/bench.py --no-cpu-baseline $ARGS > $OUT/prof_$R.log 2>&1
+echo "[profile_round] $R: FETCH_SIZE pass"
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile $ARGS --steps 2 --warmup 1 > $OUT/pmc_fetch_$R.log 2>&1
+echo "[profile_round] $R: WRITE_SIZE pass"
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$R -- python $ROOT/bench.py --no-cpu-baseline --no-kernel-profile $ARGS --steps 2 --warmup 1 > $OUT/pmc_write_$R.log 2>&1
 # keep only the small per-kernel aggregates (the raw traces exceed the 64 MiB merge cap)
 cd $ROOT
