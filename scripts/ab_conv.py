@@ -25,9 +25,11 @@ def load(path):
 
 
 def main():
-    variants = []
+    variants, dbg = [], {}
     for a in sys.argv[1:]:
         name, path = a.split("=", 1)
+        if "@" in path:            # name=path@N: diagnostic build whose kernels read SRCGAN_DBG=N (cached per kernel class at its first launch)
+            path, dbg[name] = path.split("@", 1)
         variants.append((name, load(path)))
     assert variants, __doc__
     rounds, nl = int(os.environ.get("AB_ROUNDS", "5")), int(os.environ.get("AB_N", "20"))
@@ -74,6 +76,7 @@ def main():
     for s in shapes:                     # warm-up: every variant, every shape once
         for v, h in variants:
             N._lib = h
+            os.environ["SRCGAN_DBG"] = dbg.get(v, "0")
             calls[s][0]()
     torch.cuda.synchronize()
     for r in range(rounds):

@@ -598,7 +598,8 @@ template <typename T, int MT, int NLW, bool WRES = false, int EM = 7, int NSTG =
 static int launch_ls(const ConvP& p, int ctiles, hipStream_t st) {
 #ifndef SG_NO_DIRECT_EPI
     if constexpr (MT == 1 && sizeof(T) == 2 && (EM == 0 || EM == 8 || EM == 16)) {
-        const bool direct_ok = p.Cout == 32 && p.os == 1 && p.oa == 0 && p.ob == 0 && p.YH == p.OH && p.YW == p.OW && (p.yplane == 64 ? p.ycoff % 4 == 0 : p.ycoff % 32 == 0);
+        const bool direct_ok = p.Cout == 32 && p.os == 1 && p.oa == 0 && p.ob == 0 && p.YH == p.OH && p.YW == p.OW && (p.yplane == 64 ? p.ycoff % 4 == 0 : p.ycoff % 32 == 0) &&
+                               (!p.act || (p.slope >= 0.f && p.slope <= 1.f));           // LeakyReLU as max(v, slope v)
         if (direct_ok) return (SG_DIRECT_X16 && p.vec16) ? launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 2>(p, ctiles, st) : launch_ls_dir<T, MT, NLW, WRES, EM, NSTG, PT, 1>(p, ctiles, st);
     }
 #endif

@@ -426,10 +426,81 @@ __device__ __forceinline__ void conv_direct32_sign_request(const ConvP& p, unsig
         if (ox < p.OW && oy0 + q < p.OH) sgr[q] = ((const unsigned*)p.sgn_in)[((long)b * p.OH + oy0 + q) * p.OW + ox];
     }
 }
+// One output row of the direct epilogue.  BIAS / ACT / SCALE: which of  v = alpha * (acc + bias) ; LeakyReLU  this launch needs (wave-uniform,
+// decided once per epilogue): the dense-block forward convolutions take (bias, act, alpha = 1), the gradient slices nothing but the
+// sign mask.  The epilogue is VALU-bound -- round 3 measured it: with the epilogue compiled out a 128 -> 32 launch takes 66 us,
+// with its arithmetic but no stores 82, complete 86 (scripts/ab_conv.py, SRCGAN_DBG 4 / 32), ~400 VALU instructions per row pair --
+// so every form does only its own arithmetic:
+//  * LeakyReLU as max(v, slope * v) (0 <= slope <= 1: checked by the launcher) -- 2 instructions instead of compare + multiply + select;
+//  * sign bits by  v_cmp + v_addc (m = 2 m + carry)  in element order, nibble g shifted to bit 8 g on the way: 2 instructions per
+//    element instead of compare + select + variable shift + or; the lane's half (4 h) is applied once per row;
+//  * sign words read pre-shifted by 4 h, so an element's bit is an AND with a constant.
+template <typename T, int EM, bool X16, bool BIAS, bool ACT, bool SCALE>
+__device__ __forceinline__ void conv_direct32_row(const ConvP& p, const f32x16& a, const f32x4 (&bias)[4], unsigned sgs, int h4, bool xok, bool first_half,
+                                                  char* yp, long lch0, unsigned* sgn_dst) {
+    typedef __attribute__((ext_vector_type(4))) T vec4T;
+    u32x2 pk[4];
+    unsigned m = 0u;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        const int g = (EM & 16) ? 3 - gg : gg;              // sign accumulation runs from the highest element down: bit e = element e
+        vec4T o;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = a[4 * g + i];
+            if (BIAS) v[i] += bias[g][i];
+            if (SCALE) v[i] *= p.alpha;
+            if (ACT) v[i] = fmaxf(v[i], v[i] * p.slope);
+            if (EM & 8) v[i] *= (sgs & (1u << (8 * g + i))) ? 1.f : p.mslope;
+        }
+        if (EM & 16) {
+            if (gg > 0) m <<= 4;                             // leave the 4-bit gap of the other lane half between two groups
+#pragma unroll
+            for (int i = 3; i >= 0; --i)
+                asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v[i]) : "vcc");
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = from_f<T>(v[i]);
+        if constexpr (X16) pk[g] = __builtin_bit_cast(u32x2, o);
+        else {
+            if (xok && !SG_DBG(p, 32)) *(vec4T*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
+            if (SG_DBG(p, 32)) asm volatile("" :: "v"(o));
+        }
+    }
+    if constexpr (X16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // lanes h = 0 hold channels 16j + {0..3} (pk[2j]) and 16j + 8 + {0..3} (pk[2j+1]); lanes h = 1 the +4 ones.  After the
+            // swap (upper half of x <-> lower half of y) a lane holds x', y' = channels 16j + 8h + {0..3}, + {4..7}.
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+            const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
+// Nontemporal stores: in the skeleton (scripts/hip/ingest_test.hip) they take the stores' cost away (69 -> 62.5 us); in this kernel
+// they are SLOWER (back to back 64->32 49 -> 52 us, 96->32 61 -> 66; training step 137.3 -> 140.1 ms, same-box A/B): the block's next
+// convolution reads these 32 channels straight back, and the default policy keeps them in the Infinity Cache.  Off.
+#ifndef SG_DIRECT_NT
+#define SG_DIRECT_NT 0
+#endif
+            if (xok && !SG_DBG(p, 32)) {
+                if (SG_DIRECT_NT) __builtin_nontemporal_store(o16, (u32x4*)(yp + lch0 + 32 * j));
+                else *(u32x4*)(yp + lch0 + 32 * j) = o16;
+            }
+            if (SG_DBG(p, 32)) asm volatile("" :: "v"(o16));
+        }
+    }
+    if (EM & 16) {
+        // m: nibble g at bits 8 g .. 8 g + 3 = this lane's channels 8 g + 4 h + {0..3} -> shift by 4 h and merge the two halves of the
+        // pixel (permlane32_swap of the word with itself: every lane ends up with lower | upper; no LDS round trip)
+        const unsigned mine = m << h4;
+        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        if (xok && first_half) *sgn_dst = sw[0] | sw[1];
+    }
+}
+
 template <typename T, int PT, int EM, bool X16 = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32x16 (&acc)[1][PT], const char* lds_bias,
                                                        int b, int oy0, int ox0, int lane, const unsigned* sgpre = nullptr) {
-    typedef __attribute__((ext_vector_type(4))) T vec4T;
     const int r = lane & 31, h = lane >> 5;
     const int ox = ox0 + r;
     const bool xok = ox < p.OW;
@@ -453,57 +524,28 @@ __device__ __forceinline__ void conv_epilogue_direct32(const ConvP& p, const f32
         }
         if (EM & 8) __builtin_amdgcn_s_waitcnt(0x0f70);
     }
+    // bias of this lane's 16 channels (8 g + 4 h + i): ONE set of LDS reads per unit (it was read again for every row)
+    const bool has_bias = p.bias != nullptr;
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = has_bias ? *(const f32x4*)(lds_bias + (8 * g + 4 * h) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int h4 = 4 * h;
+    const int form = (p.alpha != 1.f) ? 2 : (has_bias || p.act) ? 1 : 0;        // wave-uniform
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int oy = oy0 + q;
         if (oy >= p.OH) continue;                         // wave-uniform
         const long pix = ((long)b * p.OH + oy) * p.OW + ox;
-        const unsigned sg = sgr[q];
         char* yp = (char*)p.y + pix * p.ypix;
-        unsigned mine = 0u;
-        u32x2 pk[4];                                      // X16: the four channel groups as packed 16-bit pairs
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            vec4T o;
-            const f32x4 bias = *(const f32x4*)(lds_bias + (8 * g + 4 * h) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = (acc[0][q][4 * g + i] + bias[i]) * p.alpha;
-                if (p.act) v = v > 0.f ? v : v * p.slope;
-                if (EM & 8) v *= ((sg >> (8 * g + 4 * h + i)) & 1u) ? 1.f : p.mslope;
-                if (EM & 16) mine |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + i);
-                o[i] = from_f<T>(v);
-            }
-            if constexpr (X16) pk[g] = __builtin_bit_cast(u32x2, o);
-            else {
-                if (xok && !SG_DBG(p, 32)) *(vec4T*)(yp + lch0 + 16 * g) = o;      // dbg 32: everything but the stores (timing experiment)
-                if (SG_DBG(p, 32)) asm volatile("" :: "v"(o));
-            }
-        }
-        if constexpr (X16) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // lanes h = 0 hold channels 16j + {0..3} (pk[2j]) and 16j + 8 + {0..3} (pk[2j+1]); lanes h = 1 the +4 ones.  After the
-                // swap (upper half of x <-> lower half of y) a lane holds x', y' = channels 16j + 8h + {0..3}, + {4..7}.
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
-                const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
-// Nontemporal stores: in the skeleton (scripts/hip/ingest_test.hip) they take the stores' cost away (69 -> 62.5 us); in this kernel
-// they are SLOWER (back to back 64->32 49 -> 52 us, 96->32 61 -> 66; training step 137.3 -> 140.1 ms, same-box A/B): the block's next
-// convolution reads these 32 channels straight back, and the default policy keeps them in the Infinity Cache.  Off.
-#ifndef SG_DIRECT_NT
-#define SG_DIRECT_NT 0
-#endif
-                if (xok && !SG_DBG(p, 32)) {
-                    if (SG_DIRECT_NT) __builtin_nontemporal_store(o16, (u32x4*)(yp + lch0 + 32 * j));
-                    else *(u32x4*)(yp + lch0 + 32 * j) = o16;
-                }
-                if (SG_DBG(p, 32)) asm volatile("" :: "v"(o16));
-            }
-        }
-        if (EM & 16) {
-            const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
-            if (xok && h == 0) ((unsigned*)p.sgn_out)[pix] = mine | other;
+        unsigned* sd = (EM & 16) ? (unsigned*)p.sgn_out + pix : nullptr;
+        const unsigned sgs = sgr[q] >> h4;
+        if (form == 0) conv_direct32_row<T, EM, X16, false, false, false>(p, acc[0][q], bias, sgs, h4, xok, h == 0, yp, lch0, sd);
+        else if (form == 1) {
+            if (p.act) conv_direct32_row<T, EM, X16, true, true, false>(p, acc[0][q], bias, sgs, h4, xok, h == 0, yp, lch0, sd);
+            else conv_direct32_row<T, EM, X16, true, false, false>(p, acc[0][q], bias, sgs, h4, xok, h == 0, yp, lch0, sd);
+        } else {
+            if (p.act) conv_direct32_row<T, EM, X16, true, true, true>(p, acc[0][q], bias, sgs, h4, xok, h == 0, yp, lch0, sd);
+            else conv_direct32_row<T, EM, X16, true, false, true>(p, acc[0][q], bias, sgs, h4, xok, h == 0, yp, lch0, sd);
         }
     }
 }

@@ -372,7 +372,14 @@ def test_conv3x3_sign_masks(ops, cin, hw, dt):
     y_z = torch.zeros_like(y_m)
     ops.conv_igemm(db, wp, y_m, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), x_plane=pl, shape=(B, H, W), sign_in=sign)
     ops.conv_igemm(db, wp, y_z, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), mz=db, mz_coff=cin, x_plane=pl, mz_plane=pl, shape=(B, H, W))
-    assert torch.equal(y_m, y_z)
+    if dt == "fp16":
+        # the two forms are different kernel instances, and for _Float16 the compiler turns "f32 multiply, then round to f16" into
+        # one v_fma_mixlo_f16 (a single rounding) wherever the multiply is the last operation before the store: a handful of
+        # elements per 10^5 differ by one fp16 ulp between instances.  Same mask decisions, same f32 arithmetic.
+        d = (y_m.float() - y_z.float()).abs()
+        assert float((d / y_z.float().abs().clamp_min(2.0 ** -14)).max()) <= 2.0 ** -10 and int((d > 0).sum()) <= 1e-4 * d.numel(), int((d > 0).sum())
+    else:
+        assert torch.equal(y_m, y_z)
     # refused: 64 output channels, interleaved input
     y64 = torch.zeros(B, H, W, 64, device="cuda", dtype=db.dtype)
     with pytest.raises(RuntimeError):
