@@ -47,7 +47,7 @@ def main():
     del act, grd
     calls = {}
     for s in shapes:
-        fwd, cin = s[0] == "f", int(s[1:4].rstrip("r"))
+        fwd, cin = s[0] == "f", int(s[1:4].rstrip("rn"))
         cout = 64 if cin == 192 else 32
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         wp = ops.pack_conv2d_fwd(w, dt)
@@ -57,6 +57,9 @@ def main():
             k = (cin - 64) // 32
             f = (lambda wp=wp, b=b, cin=cin, k=k: ops.conv_igemm(A, wp, A, kh=3, kw=3, Cin=cin, Cout=32, y_coff=cin, pad=(1, 1), bias=b, act=True,
                                                                  x_plane=pl, y_plane=pl, shape=(B, H, W), sign_out=sign[k]))
+        elif fwd and s.endswith("n"):    # conv5 without its residual operand (what the operand costs: compare with f192)
+            f = (lambda wp=wp, b=b: ops.conv_igemm(A, wp, nxt, kh=3, kw=3, Cin=192, Cout=64, pad=(1, 1), bias=b, alpha=0.2,
+                                                    x_plane=pl, y_plane=pl, shape=(B, H, W)))
         elif fwd:                        # conv5: 0.2 * (conv + bias) + x  -> channels [0, 64) of the next buffer
             f = (lambda wp=wp, b=b: ops.conv_igemm(A, wp, nxt, kh=3, kw=3, Cin=192, Cout=64, pad=(1, 1), bias=b, alpha=0.2, r1=A, r1_cend=64, beta1=1.0,
                                                     x_plane=pl, y_plane=pl, r1_plane=pl, shape=(B, H, W)))

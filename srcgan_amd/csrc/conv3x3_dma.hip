@@ -466,15 +466,20 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
     static_assert((PT == 2 || PT == 4) && PD >= 1 && PD <= 5, "A-ring sizing");
     // byte offsets inside a stage (stage 0), k-half 0; k-half 1 is the same address with bit 5 flipped (slot ^ 2)
     int pb[NGRP], pa;
-    {
-        const int L0 = wave * PT * IWT + r;
+    int L0 = wave * PT * IWT + r;
+    auto calc_pb = [&]() {
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             const int lp = L0 + (g / 3) * IWT + (g % 3);
             pb[g] = lp * 64 + ((h ^ ((lp >> 2) & 3)) * 16);
         }
-        pa = (WRES ? NSTG * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
-    }
+    };
+    // 64-row tiles with residual operands: the epilogue holds those operands in registers from the pre-epilogue barrier on (64 VGPRs
+    // beside the 64 accumulators, 168 in all), so the 12 fragment offsets are rebuilt per chunk (~40 VALU beside 216 MFMAs) instead
+    // of living across the epilogue
+    constexpr bool PB_PER_CHUNK = MT == 2 && DIR == 3 && (EM & 2) != 0;      // (one operand: 164 VGPRs without)
+    if constexpr (!PB_PER_CHUNK) calc_pb();
+    pa = (WRES ? NSTG * SBYTES : HBYTES) + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);      // resident weights: + c * WCH, stage-independent
     int stage = 0;
     [[maybe_unused]] int trk = 0;
     for (int u = u0; u < u_hi; u += gw) {
@@ -505,6 +510,7 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
             }
 #endif
             if (SG_DBG(p, 1)) continue;
+            if constexpr (PB_PER_CHUNK) { asm volatile("" : "+v"(L0)); calc_pb(); }
             const char* ls = smem + stage * SBYTES;
             const char* lsw = WRES ? smem + c * WCH : ls;
             frag_t fa[NRA][MT], fb[NRB];
@@ -569,13 +575,15 @@ __global__ __launch_bounds__((16 / PT + NLW) * 64) void conv3x3_ls_k(const ConvP
 #ifdef SG_TRACE
             const unsigned long long t_pre = __builtin_amdgcn_s_memrealtime();
 #endif
+            ConvRowsPre<T, MT, PT, EM> pre;
+            if (!SG_DBG(p, 4)) conv_lds_rows_request<T, MT, PT, EM>(p, pre, cb, cct, coy0 + wave * PT, cox0, lane);      // in flight across the barrier
             sg_barrier_lds();
 #ifdef SG_TRACE
             const unsigned long long t_eb = __builtin_amdgcn_s_memrealtime();
 #endif
             char* tsp = smem + (stage == 0 ? NSTG - 1 : stage - 1) * SBYTES + wave * (32 * ERS);      // the stage just consumed: refilled only after the next chunk barrier
             if (!SG_DBG(p, 4))
-                conv_epilogue_lds_rows<T, MT, PT, EM>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane);
+                conv_epilogue_lds_rows<T, MT, PT, EM>(p, acc, tsp, smem + bias_off, cb, cct, coy0 + wave * PT, cox0, lane, pre);
 #ifdef SG_TRACE
             if (p.trace && blockIdx.x == 8 && wave == 0 && lane == 0 && trk <= 60) {
                 p.trace[(trk - 1) * 8 + 3] = t_pre; p.trace[(trk - 1) * 8 + 6] = t_eb; p.trace[(trk - 1) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -625,6 +633,11 @@ static int launch_ls_dir(const ConvP& p, int ctiles, hipStream_t st) {
         SG_HIP(hipGetDevice(&dev)); SG_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount;
         attr_set = true;
+    }
+    if constexpr (DIR == 3 && ConvRowsPre<T, MT, PT, EM>::ON) {       // 32-bit per-lane offsets of the residual operands' buffer loads (conv_lds_rows_request)
+        const long lim = (1L << 31) - (1L << 20);
+        SG_REQUIRE((!p.r1 || p.r1plane < lim) && (!p.r2 || p.r2plane < lim) && p.r1pix < (1 << 16) && p.r2pix < (1 << 16),
+                   "conv3x3: a residual operand's channel plane must be below 2 GiB");
     }
     ConvP q = p;
     q.tiles_x = cdiv(p.OW, 32); q.tiles_y = cdiv(p.OH, 16); q.ctiles = ctiles;

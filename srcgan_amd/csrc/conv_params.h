@@ -266,9 +266,57 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x
 // EM: which optional operands this instantiation can take (1 = r1, 2 = r2, 4 = mz, 8 = sign mask read, 16 = sign mask write;
 // the masks need MT == 1, 8 channels per lane and os == 1: byte (c0 / 8) of the pixel's u32); the others compile away, with
 // their addressing and the scalar registers it pins (the all-operand form spills ~100 SGPRs and runs ~1000 instructions).
+// The residual operands of a 64-row tile (conv5 / block-input gradient), ALL rows and passes of the wave, as requested by
+// conv_lds_rows_request: the 3x3 kernel calls it BEFORE the barrier in front of its epilogue, so the operands' memory latency runs
+// under the barrier wait (traced ~1.4 us per unit) instead of after it.  Requested inside the epilogue, the first operand cost
+// 10 us per 192 -> 64 launch (194.6 -> 204.3 us) and the second one, requested row by row for want of registers beside the loop's
+// fragment rings -- which are dead at the barrier --, another 27 us (206.7 -> 233.5 us; scripts/ab_conv.py f192n / f192 / b192 / b192r).
+template <typename T, int MT, int PT, int EM>
+struct ConvRowsPre {
+    static constexpr int EPP = DT<T>::EPP, NP = 32 / (64 / (32 * MT / EPP));
+    static constexpr bool ON = MT == 2 && sizeof(T) == 2 && NP * 4 * 2 <= 32 && (EM & 3) != 0 && (EM & ~3) == 0;
+    u32x4 r1[ON && (EM & 1) ? PT : 1][ON && (EM & 1) ? NP : 1];
+    u32x4 r2[ON && (EM & 2) ? PT : 1][ON && (EM & 2) ? NP : 1];
+};
+// Buffer loads, not global loads behind `if (in range)`: exec-masked blocks made hipcc wait for every load on its own
+// (s_waitcnt vmcnt(0) + a scratch spill after each of the 16).  One descriptor per row and operand -- base = the row segment's
+// first pixel in the plane of the tile's first channel, everything wave-uniform --, the pass as scalar offset, one per-lane
+// 32-bit offset (pixel within the pass, channel, plane) that is swapped for an out-of-range one where the lane has no work: the
+// hardware range check returns zeros for it.  Needs lane offsets < 2^32: planes below 2 GiB (checked at launch).
+template <typename T, int MT, int PT, int EM>
+__device__ __forceinline__ void conv_lds_rows_request(const ConvP& p, ConvRowsPre<T, MT, PT, EM>& pre, int b, int ct, int oy0, int ox0, int lane) {
+    if constexpr (ConvRowsPre<T, MT, PT, EM>::ON) {
+        constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
+        constexpr unsigned OOB = 0xffffffffu;
+        const int lx = lane / LPP, co0 = ct * COT + (lane % LPP) * EPP;
+        const bool cok = co0 < p.Cout;
+        const bool use_r1 = (EM & 1) && p.r1 && cok && co0 < p.r1cend, use_r2 = (EM & 2) && p.r2 && cok && co0 < p.r2cend;
+        const long lstep = (long)lx * p.os;
+        const long u1 = (EM & 1) ? (long)chan_off<T>(p.r1coff + ct * COT, p.r1plane) : 0, u2 = (EM & 2) ? (long)chan_off<T>(p.r2coff + ct * COT, p.r2plane) : 0;
+        const unsigned l1 = use_r1 ? (unsigned)(lstep * p.r1pix + (long)chan_off<T>(p.r1coff + co0, p.r1plane) - u1) : OOB;
+        const unsigned l2 = use_r2 ? (unsigned)(lstep * p.r2pix + (long)chan_off<T>(p.r2coff + co0, p.r2plane) - u2) : OOB;
+        const int xrem = p.OW - ox0 - lx;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const int oy = oy0 + q;
+            const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
+            const unsigned nrec = oy < p.OH ? 0xfffffff0u : 0u;
+            [[maybe_unused]] __amdgpu_buffer_rsrc_t d1, d2;
+            if constexpr ((EM & 1) != 0) d1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r1 + u1 + rowpix * p.r1pix), 0, (EM & 1) && p.r1 ? nrec : 0u, 0x00020000);
+            if constexpr ((EM & 2) != 0) d2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r2 + u2 + rowpix * p.r2pix), 0, (EM & 2) && p.r2 ? nrec : 0u, 0x00020000);
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const bool ok = pass * PPP < xrem;
+                if constexpr ((EM & 1) != 0) pre.r1[q][pass] = __builtin_amdgcn_raw_buffer_load_b128(d1, ok ? l1 : OOB, pass * PPP * p.os * (int)p.r1pix, 0);
+                if constexpr ((EM & 2) != 0) pre.r2[q][pass] = __builtin_amdgcn_raw_buffer_load_b128(d2, ok ? l2 : OOB, pass * PPP * p.os * (int)p.r2pix, 0);
+            }
+        }
+    }
+}
+
 template <typename T, int MT, int PT, int EM = 7>
 __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32x16 (&acc)[MT][PT], char* lds_wave, const char* lds_bias,
-                                                       int b, int ct, int oy0, int ox0, int lane) {
+                                                       int b, int ct, int oy0, int ox0, int lane, const ConvRowsPre<T, MT, PT, EM>& pre) {
     constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
     constexpr int RS = COT * 4 + 16;
     constexpr bool PF = NP * 4 * 2 <= 32;            // prefetch the operands of a whole row when that costs <= 32 VGPRs
@@ -295,29 +343,14 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
     const long ls = (long)lx * 4 + (c0 >> 3);          // mask byte of this lane's 8 channels
     const int xrem = p.OW - ox0 - lx;                // pass k is in range iff k * PPP < xrem
     // 64-row tiles (conv5 / block-input gradient: residual operands, 168-VGPR budget): the residual operands of ALL rows
-    // and passes are requested before the first row is processed.  Per-row requests exposed one memory latency per row --
-    // traced 4.2 us of epilogue per 25 us unit at 192->64 -- and the second residual was loaded at its use, once per pass.
-    constexpr bool PFALL = MT == 2 && PF && (EM & 3) != 0 && (EM & ~3) == 0;
-    vecT r1a[PFALL ? PT : 1][PFALL ? NP : 1];      // (the second residual per row: both for all rows would spill)
-    if constexpr (PFALL) {
-#pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            const int oy = oy0 + q;
-            const bool rok = cok && oy < p.OH;
-            const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const bool ok = rok && pass * PPP < xrem;
-                const long px = rowpix + pass * (long)PPP * p.os;
-                if (use_r1 && ok) r1a[q][pass] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
-            }
-        }
-        // One explicit wait for these loads.  Without it the compiler puts `s_waitcnt vmcnt(0)` at the head of EVERY pass (the
-        // passes are exec-masked blocks and its pending-load state is merged conservatively at their joins), and on gfx9
-        // vmcnt counts stores too: each pass then waited for the previous pass's store to be acknowledged by memory
-        // (~0.45 us each, 3.6 us per unit: the ISA showed the waits, the trace the time).
-        if (!(EM & 2)) __builtin_amdgcn_s_waitcnt(0x0f70);
-    }
+    // and passes arrive in `pre` (requested in front of the pre-epilogue barrier, conv_lds_rows_request).
+    constexpr bool PFALL = ConvRowsPre<T, MT, PT, EM>::ON;
+    static_assert(!PFALL || PF, "prefetch sizing");
+    // One explicit wait for these loads.  Without it the compiler puts `s_waitcnt vmcnt(0)` at the head of EVERY pass (the
+    // passes are exec-masked blocks and its pending-load state is merged conservatively at their joins), and on gfx9
+    // vmcnt counts stores too: each pass then waited for the previous pass's store to be acknowledged by memory
+    // (~0.45 us each, 3.6 us per unit: the ISA showed the waits, the trace the time).
+    if constexpr (PFALL) __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int oy = oy0 + q;
@@ -326,14 +359,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
         const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + (long)ox0 * p.os + p.ob;
         const long pstep = (long)PPP * p.os;
         vecT r1v[NPF], mzv[NPF];
-        vecT r2row[PFALL ? NP : 1];
         unsigned sgv[NPF];
-        if constexpr (PFALL) {
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass)
-                if (use_r2 && rok && pass * PPP < xrem) r2row[pass] = *(const vecT*)((const char*)p.r2 + (rowpix + pass * pstep) * p.r2pix + l2);
-            if (EM & 2) __builtin_amdgcn_s_waitcnt(0x0f70);      // once per row (also the previous row's stores), not once per pass
-        }
         if (PF && !PFALL) {
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
@@ -369,12 +395,14 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
             if (use_r1) {
-                const vecT t = PFALL ? r1a[PFALL ? q : 0][PFALL ? pass : 0] : r1v[pass % NPF];
+                vecT t;
+                if constexpr (PFALL && (EM & 1) != 0) t = __builtin_bit_cast(vecT, pre.r1[q][pass]);
+                else t = r1v[pass % NPF];
 #pragma unroll
                 for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(t[i]); }
             if (use_r2) {
                 vecT t;
-                if constexpr (PFALL) t = r2row[pass];
+                if constexpr (PFALL && (EM & 2) != 0) t = __builtin_bit_cast(vecT, pre.r2[q][pass]);
                 else t = *(const vecT*)((const char*)p.r2 + px * p.r2pix + l2);
 #pragma unroll
                 for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
