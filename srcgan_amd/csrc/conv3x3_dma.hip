@@ -183,7 +183,7 @@ __global__ __launch_bounds__((NWV + NLW) * 64) void conv3x3_dma_k(const ConvP p)
         if (SG_DBG(p, 4)) continue;
         // ---- epilogue of the finished unit; the next unit's first chunk is already in flight into `stage`
         // (the loop increment flipped it), so the transpose space is the OTHER stage = the one just computed from.
-        if (p.vec16) {
+        if (p.buf16) {
             __syncthreads();      // every wave finished reading the last chunk before its stage is reused (loaders join)
             if (loader) continue;
             char* tsp = smem + (stage ^ 1) * SBYTES + wave * (32 * ERS);

@@ -148,24 +148,27 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     // WPK (4x4 and larger kernels): one kernel row of weights in LDS at a time (LDS budget).  The row is prefetched into
     // registers one row ahead -- while the previous row's MFMAs run -- so its L2 latency is not exposed between two
     // barriers (it was: 16 MFMAs per wave against a 1-2 us load, matrix pipe 22 % busy on the 4x4 stride-2 layers).
-    u32x4 wv[WPK ? WIT : 1];
-    auto issue_wrow = [&](int c, int ky) {
+    // Two rows ahead (even KH): one row's MFMA phase is 16-32 MFMAs per wave, 0.25-0.5 us -- less than the L2 round trip of the
+    // row's loads, which was exposed once per kernel row (4x4 stride-2 layers: 16 rows per workgroup).
+    constexpr int WPD = (WPK && KH % 2 == 0) ? 2 : 1;
+    u32x4 wv[WPD][WPK ? WIT : 1];
+    auto issue_wrow = [&](int c, int ky, int slot) {
         if (IG_DBG(p, 8) && (c > 0 || ky > 0)) return;
         if constexpr (WPK) {
             const char* ws = wb + ((size_t)c * NTAP + (size_t)ky * KW) * COT * 64;
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int pc = it * 256 + tid;
-                wv[it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
+                wv[slot][it] = *(const u32x4*)(ws + (size_t)((WIT * 256 == NPW || pc < NPW) ? pc : 0) * 16);
             }
         }
     };
-    auto write_wrow = [&]() {
+    auto write_wrow = [&](int slot) {
         if constexpr (WPK) {
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int pc = it * 256 + tid;
-                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wv[it];
+                if (WIT * 256 == NPW || pc < NPW) *(u32x4*)(lds_w + (pc >> 2) * PIXB + part * 16) = wv[slot][it];
             }
         }
     };
@@ -177,84 +180,77 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         if (!(IG_DBG(p, 16) && c > 0)) {
             write_halo(c, rs);
             write_w(rs);
-            write_wrow();             // kernel row 0 of this chunk
+            write_wrow(0);            // kernel row 0 of this chunk
         }
         __syncthreads();
         if (c + NRS < p.nchunk) {     // prefetch into the registers just drained: in flight while NRS chunks' MFMAs run
             issue_halo(c + NRS, rs);
             issue_w(c + NRS, rs);
         }
+        // Fragment reads run ONE step (tap column, k-half) ahead of the MFMAs, in a register double buffer.  As plain
+        // "read, then multiply" code hipcc emitted `ds_read x3, s_waitcnt lgkmcnt(0), v_mfma` per step (ISA of the 4x4 stride-2
+        // layers): every MFMA behind an exposed LDS latency, matrix pipe 28 % busy with 2 waves per SIMD.
+        // Two steps ahead where a step has only one or two MFMAs per wave (64 cycles: less than an LDS round trip).
+        using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, bf16x8>::type;
+        constexpr int NSTEP = KW * 2, NFLAT = WPK ? NSTEP : KH * NSTEP;      // WPK: the ring restarts with every kernel row (its weights are rewritten)
+        constexpr int PD = (MT * PT <= 2 && NSTEP >= 4) ? 2 : 1, NB = PD + 1;
+        frag_t fa[NB][MT], fb[NB][PT];
+        auto rd = [&](int kyw, int g) {          // flat step g of the ring; kyw = the kernel row in LDS (WPK)
+            const int ky = WPK ? kyw : g / NSTEP, s2 = g % NSTEP;
+            const int kx = s2 >> 1, ks = s2 & 1;
+            const int tapw = WPK ? kx : ky * KW + kx;
+            const int koff = ks * 32 + h * 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                fa[g % NB][m] = *(const frag_t*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+                fb[g % NB][q] = *(const frag_t*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
+        };
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
             if constexpr (WPK) {
                 if (ky > 0) {
                     __syncthreads();  // the previous row's readers are done
-                    if (!IG_DBG(p, 16)) write_wrow();
+                    if (!IG_DBG(p, 16)) write_wrow(ky % WPD);
                     __syncthreads();
                 }
-                if (ky + 1 < KH) issue_wrow(c, ky + 1);
-                else if (c + 1 < p.nchunk) issue_wrow(c + 1, 0);
+                // the row WPD ahead, into the registers just written out
+                if (ky + WPD < KH) issue_wrow(c, ky + WPD, ky % WPD);
+                else if (c + 1 < p.nchunk) issue_wrow(c + 1, ky + WPD - KH, ky % WPD);
+            }
+            if (WPK || ky == 0) {
+#pragma unroll
+                for (int g = 0; g < PD; ++g) rd(ky, g);
             }
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-                const int tapw = WPK ? kx : ky * KW + kx;
+            for (int s2 = 0; s2 < NSTEP; ++s2) {
+                const int g = (WPK ? 0 : ky * NSTEP) + s2;
+                if (g + PD < NFLAT) rd(ky, g + PD);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int koff = ks * 32 + h * 16;
-                    if constexpr (std::is_same<T, float>::value) {
-                        f32x4 a[MT], bb[PT];
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            a[m] = *(const f32x4*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
+                    for (int q = 0; q < PT; ++q) {
+                        if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-                        for (int q = 0; q < PT; ++q)
-                            bb[q] = *(const f32x4*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                                for (int q = 0; q < PT; ++q)
-                                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bb[q][j], acc[m][q], 0, 0, 0);
-                    } else {
-                        bf16x8 a[MT], bb[PT];
-                        if (!IG_DBG(p, 32)) {
-#pragma unroll
-                            for (int m = 0; m < MT; ++m)
-                                a[m] = *(const bf16x8*)(lds_w + (tapw * COT + m * 32 + r) * PIXB + koff);
-#pragma unroll
-                            for (int q = 0; q < PT; ++q)
-                                bb[q] = *(const bf16x8*)(lds_h + (((wave * PT + q) * S + ky) * IWT + r * S + kx) * PIXB + koff);
-                        } else {
-                            const u32x4 stale = {0x3f803f80u ^ (unsigned)lane, 0x3f003f00u, 0x3e803e80u ^ (unsigned)c, 0x3f803f80u};
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) a[m] = __builtin_bit_cast(bf16x8, stale);
-#pragma unroll
-                            for (int q = 0; q < PT; ++q) bb[q] = __builtin_bit_cast(bf16x8, stale);
-                        }
-                        if (IG_DBG(p, 1)) {              // keep the fragment reads alive without the matrix pipe
-                            u32x4 t = {0u, 0u, 0u, 0u};
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) t ^= __builtin_bit_cast(u32x4, a[m]);
-#pragma unroll
-                            for (int q = 0; q < PT; ++q) t ^= __builtin_bit_cast(u32x4, bb[q]);
+                            for (int j = 0; j < 4; ++j)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g % NB][m][j], fb[g % NB][q][j], acc[m][q], 0, 0, 0);
+                        } else if (IG_DBG(p, 1)) {      // keep the fragment reads alive without the matrix pipe
+                            const u32x4 t = __builtin_bit_cast(u32x4, fa[g % NB][m]) ^ __builtin_bit_cast(u32x4, fb[g % NB][q]);
                             acc[0][0][0] += __builtin_bit_cast(float, t[0] ^ t[1] ^ t[2] ^ t[3]);
-                        } else {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int q = 0; q < PT; ++q)
-                                acc[m][q] = sg_mfma16<T>(a[m], bb[q], acc[m][q]);
-                        }
+                        } else
+                            acc[m][q] = sg_mfma16<T>(fa[g % NB][m], fb[g % NB][q], acc[m][q]);
                     }
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();   // all waves are done reading this chunk's LDS image
     };
     issue_halo(0, RS0{});
     issue_w(0, RS0{});
-    issue_wrow(0, 0);
+    issue_wrow(0, 0, 0);
+    if constexpr (WPD == 2) issue_wrow(0, 1, 1);
     if constexpr (NRS == 2) {
         if (p.nchunk > 1) { issue_halo(1, RS1{}); issue_w(1, RS1{}); }
         for (int c = 0; c < p.nchunk; c += 2) {
@@ -281,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         if (keep == 1.2345e-30f) *(float*)p.y = keep;
         return;
     }
-    if (p.vec16) {
+    if (p.buf16) {
         constexpr int RS = COT * 4 + 16;
         char* lw = smem + wave * 32 * RS;
 #pragma unroll
@@ -402,6 +398,11 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->r1 || (me(d->r1_cs) && me(d->r1_coff) && me(d->r1_cend))) &&
                   (!d->r2 || (me(d->r2_cs) && me(d->r2_coff) && me(d->r2_cend))) &&
                   (!d->mz || (me(d->mz_cs) && me(d->mz_coff) && me(d->mz_c0)));
+    }
+    {
+        const long lim = (1L << 31) - (1L << 20);
+        p.buf16 = p.vec16 && p.yplane < lim && p.ypix < (1 << 20) && (!d->r1 || (p.r1plane < lim && p.r1pix < (1 << 20))) &&
+                  (!d->r2 || (p.r2plane < lim && p.r2pix < (1 << 20))) && (!d->mz || (p.mzplane < lim && p.mzpix < (1 << 20)));
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->npar) {

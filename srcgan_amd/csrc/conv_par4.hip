@@ -169,7 +169,7 @@ template <typename T, int PT>
 static int launch_par4(const ConvP& p, hipStream_t st) {
     // only the LDS-transposed epilogue (16-byte accessible operands) is instantiated: the per-element form spills beside the 128
     // accumulator registers; callers with odd channel counts keep the four separate parity launches
-    SG_REQUIRE(p.vec16, "srcgan_conv_igemm: npar == 4 needs output / mask channels, strides and offsets that are multiples of 16 bytes");
+    SG_REQUIRE(p.buf16, "srcgan_conv_igemm: npar == 4 needs output / mask channels, strides and offsets that are multiples of 16 bytes (and channel planes below 2 GiB)");
     return launch_par4v<T, PT, true>(p, st);
 }
 

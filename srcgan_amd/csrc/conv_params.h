@@ -17,6 +17,7 @@ struct ConvP {
     float alpha, beta1, beta2, slope, mslope;
     int act, vec, nchunk, tiles_x, tiles_y, ctiles;
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
+    int buf16;    // vec16, and every epilogue tensor's channel plane is below 2 GiB: the row epilogue's 32-bit buffer offsets (conv_epilogue_lds_row)
     int rev;      // images are walked last to first
     long wpar;    // dgrad_s2k4 (conv_par4.hip): bytes between the packs of consecutive output parities
     unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
@@ -167,39 +168,57 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, const f32x16 (
 }
 
 // One output row (32 pixels) of the LDS-transposed epilogue: transpose space = 32 * (COT*4+16) bytes per wave.
+// Every operand access is a BUFFER access: one descriptor per operand and row whose base (image, row, first pixel of the tile, plane
+// of the tile's first channel) is wave-uniform, the pass as scalar offset, and one 32-bit per-lane offset (pixel within the pass,
+// channel) that is swapped for an out-of-range one where the lane has no work -- the range check returns zeros / drops the store.
+// No exec-masked blocks: the older form (global loads and stores behind `if (in range)`, a 64-bit multiply per access) made hipcc
+// wait for loads one by one and put `s_waitcnt vmcnt(0)` -- which on gfx9 counts stores -- at the head of every pass (ISA of the
+// 4x4 stride-2 layers), in kernels whose workgroups run 2-8 K chunks between prologue and epilogue.  All operands of the row are
+// requested before the transposition.  Needs per-lane offsets below 2^32: channel planes below 2 GiB (checked at launch).
 template <typename T, int MT, int PT>
 __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
                                                            int oy, int ox0, int lane) {
-    constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP;
+    constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
     constexpr int RS = COT * 4 + 16;
+    constexpr unsigned OOB = 0xffffffffu, FLAGS = 0x00020000u;
+    static_assert(EPP * sizeof(T) == 16, "16-byte operand accesses");
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
     const int r = lane & 31, h = lane >> 5;
-    const int cpart = lane % LPP, c0 = cpart * EPP, co0 = ct * COT + c0;
+    const int lx = lane / LPP, c0 = (lane % LPP) * EPP, co0 = ct * COT + c0;
     const bool cok = co0 < p.Cout;
     float bias[EPP];
+    {
+        const __amdgpu_buffer_rsrc_t db = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.Cout * 4 : 0, FLAGS);
 #pragma unroll
-    for (int i = 0; i < EPP; ++i) bias[i] = 0.f;
-    if (p.bias && cok) {
-#pragma unroll
-        for (int i = 0; i < EPP; i += 4) { const f32x4 bv = *(const f32x4*)(p.bias + co0 + i); bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3]; }
+        for (int i = 0; i < EPP; i += 4) {
+            const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(db, (co0 + i) * 4, 0, 0));
+            bias[i] = bv[0]; bias[i + 1] = bv[1]; bias[i + 2] = bv[2]; bias[i + 3] = bv[3];
+        }
     }
-    const bool use_r1 = p.r1 && co0 < p.r1cend, use_r2 = p.r2 && co0 < p.r2cend, use_mz = p.mz && co0 >= p.mzc0;
-    typedef __attribute__((ext_vector_type(EPP))) T vecT;
-    constexpr int NP = 32 / PPP;
-    // The first residual and the activation-mask operand of ALL passes of the row are requested here, before the transposition:
-    // loaded inside the pass loop each exposed one memory latency per pass (a stride-2 parity gradient 128 -> 64 channels with
-    // its LeakyReLU mask: 147 -> 136 us, 118 us without the mask; -DSG_EPI_PF=0, scripts/microbench_generic.py).
-#ifndef SG_EPI_PF
-#define SG_EPI_PF 1
-#endif
-    vecT r1v[NP], mzv[NP];
-    const bool rowok = cok && oy < p.OH;
-    const size_t rowpix = ((size_t)b * p.YH + (size_t)oy * p.os + p.oa) * p.YW + p.ob;
+    const bool use_r1 = p.r1 && cok && co0 < p.r1cend, use_r2 = p.r2 && cok && co0 < p.r2cend, use_mz = p.mz && cok && co0 >= p.mzc0;
+    const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + p.ob + (long)ox0 * p.os;       // wave-uniform: first pixel of pass 0
+    const unsigned nrec = oy < p.OH ? 0xfffffff0u : 0u;
+    const int xrem = p.OW - ox0 - lx;                // pass k is in range for this lane iff k * PPP < xrem
+    const long lstep = (long)lx * p.os;
+    const int ctc = ct * COT;
+    const long uy = (long)chan_off<T>(p.ycoff + ctc, p.yplane), u1 = (long)chan_off<T>(p.r1coff + ctc, p.r1plane);
+    const long u2 = (long)chan_off<T>(p.r2coff + ctc, p.r2plane), um = (long)chan_off<T>(p.mzcoff + ctc, p.mzplane);
+    const unsigned ly = cok ? (unsigned)(lstep * p.ypix + (long)chan_off<T>(p.ycoff + co0, p.yplane) - uy) : OOB;
+    const unsigned l1 = use_r1 ? (unsigned)(lstep * p.r1pix + (long)chan_off<T>(p.r1coff + co0, p.r1plane) - u1) : OOB;
+    const unsigned l2 = use_r2 ? (unsigned)(lstep * p.r2pix + (long)chan_off<T>(p.r2coff + co0, p.r2plane) - u2) : OOB;
+    const unsigned lm = use_mz ? (unsigned)(lstep * p.mzpix + (long)chan_off<T>(p.mzcoff + co0, p.mzplane) - um) : OOB;
+    const __amdgpu_buffer_rsrc_t dy = __builtin_amdgcn_make_buffer_rsrc((char*)p.y + uy + rowpix * p.ypix, 0, nrec, FLAGS);
+    const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r1 + u1 + rowpix * p.r1pix), 0, p.r1 ? nrec : 0u, FLAGS);
+    const __amdgpu_buffer_rsrc_t d2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r2 + u2 + rowpix * p.r2pix), 0, p.r2 ? nrec : 0u, FLAGS);
+    const __amdgpu_buffer_rsrc_t dm = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.mz + um + rowpix * p.mzpix), 0, p.mz ? nrec : 0u, FLAGS);
+    const int sy = PPP * p.os * (int)p.ypix, s1 = PPP * p.os * (int)p.r1pix, s2 = PPP * p.os * (int)p.r2pix, sm = PPP * p.os * (int)p.mzpix;
+    u32x4 r1v[NP], r2v[NP], mzv[NP];
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
-        const int ox = ox0 + pass * PPP + lane / LPP;
-        const size_t opix = rowpix + (size_t)ox * p.os;
-        if (SG_EPI_PF && use_r1 && rowok && ox < p.OW) r1v[pass] = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
-        if (SG_EPI_PF && use_mz && rowok && ox < p.OW) mzv[pass] = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
+        const bool in = pass * PPP < xrem;
+        r1v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d1, in ? l1 : OOB, pass * s1, 0);
+        r2v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d2, in ? l2 : OOB, pass * s2, 0);
+        mzv[pass] = __builtin_amdgcn_raw_buffer_load_b128(dm, in ? lm : OOB, pass * sm, 0);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -210,44 +229,32 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         }
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
-        const int pix = pass * PPP + lane / LPP;
-        const int ox = ox0 + pix;
         float v[EPP];
 #pragma unroll
         for (int i = 0; i < EPP; i += 4) {
-            const f32x4 t = *(const f32x4*)(lds_wave + pix * RS + (c0 + i) * 4);
+            const f32x4 t = *(const f32x4*)(lds_wave + (pass * PPP + lx) * RS + (c0 + i) * 4);
             v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
-        if (!rowok || ox >= p.OW) continue;
-        const size_t opix = rowpix + (size_t)ox * p.os;
+        const vecT a1 = __builtin_bit_cast(vecT, r1v[pass]), a2 = __builtin_bit_cast(vecT, r2v[pass]), am = __builtin_bit_cast(vecT, mzv[pass]);
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (!SG_EPI_PF) {
-            if (use_r1) r1v[pass] = *(const vecT*)((const char*)p.r1 + opix * p.r1pix + chan_off<T>(p.r1coff + co0, p.r1plane));
-            if (use_mz) mzv[pass] = *(const vecT*)((const char*)p.mz + opix * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane));
-        }
-        if (use_r1) {
+        if (p.r1) {                     // wave-uniform conditions: scalar branches, not exec masks (lanes outside their operand hold zeros)
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(r1v[pass][i]); }
-        if (use_r2) { const vecT t = *(const vecT*)((const char*)p.r2 + opix * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane));
+            for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(a1[i]); }
+        if (p.r2) {
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(t[i]); }
+            for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(a2[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (use_mz) {
+        if (p.mz) {
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] *= (to_f(mzv[pass][i]) > 0.f ? 1.f : p.mslope); }
+            for (int i = 0; i < EPP; ++i) v[i] *= (!use_mz || to_f(am[i]) > 0.f) ? 1.f : p.mslope; }
         vecT o;
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
-        *(vecT*)((char*)p.y + opix * p.ypix + chan_off<T>(p.ycoff + co0, p.yplane)) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, pass * PPP < xrem ? ly : OOB, pass * sy, 0);
     }
-    // consume the bias registers on every path: a load left "pending" at the end of the epilogue makes hipcc drain
-    // vmcnt(0) at the next write of those registers -- inside the main loop, once per stage (measured: it
-    // serialised the LDS-DMA ring).
-#pragma unroll
-    for (int i = 0; i < EPP; ++i) asm volatile("" :: "v"(bias[i]));
 }
 template <typename T, int MT, int PT>
 __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
