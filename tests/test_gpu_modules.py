@@ -88,13 +88,15 @@ def test_rddbnet_full_width_vs_oracle(dt, tol):
     assert worst < tol * 2, worst
 
 
-def _rddbnet_depth_case(dt, hw=64, emulate=False, exact=False):
+def _rddbnet_depth_case(dt, hw=64, emulate=False, exact=False, store_dtype=torch.bfloat16, trunk_scale=1.0, loss_scale=1.0):
     """The generator at the depth the benchmark runs (BASELINE configs[1]: RDDBNet(3,3,4,nb=23), 345 stacked convolutions) on one
     3 x hw x hw crop against the CPU oracle: output, input gradient and all 697 parameter gradients.  MSE loss: L1's gradient
     sign(y - t) flips discretely where y ~ t, which says nothing about the kernels.  emulate: the oracle stores activations and
     conv weights in bf16 like the native perf mode (oracle.storage).  exact: the oracle in float64."""
     from srcgan_amd import RDDBNet, MSELoss
     sd = oracle.rddbnet_state(3, 3, 4, 64, 23, 32, seed=7)
+    if trunk_scale != 1.0:      # ESRGAN's 0.1 x initialisation of the trunk convolutions (what the fp16 bench line runs: bench.py --init-scale)
+        sd = {k: (v * trunk_scale if k.endswith("weight") and v.dim() == 4 and "RRDB_trunk" in k else v) for k, v in sd.items()}
     g = torch.Generator().manual_seed(11)
     x = torch.rand(1, 3, hw, hw, generator=g)
     t = torch.rand(1, 3, 4 * hw, 4 * hw, generator=g)
@@ -103,7 +105,7 @@ def _rddbnet_depth_case(dt, hw=64, emulate=False, exact=False):
         ref_sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
         xr = x.clone().to(dtype).requires_grad_(True)
         if store:
-            with oracle.storage(torch.bfloat16):
+            with oracle.storage(store_dtype):
                 yr = oracle.rddbnet_forward(ref_sd, xr, 4)
         else:
             yr = oracle.rddbnet_forward(ref_sd, xr, 4)
@@ -113,9 +115,9 @@ def _rddbnet_depth_case(dt, hw=64, emulate=False, exact=False):
     net = _load(RDDBNet(3, 3, 4, nf=64, nb=23, gc=32, dtype=dt), sd)
     xg = x.cuda().requires_grad_(True)
     y = net(xg)
-    MSELoss()(y, t.cuda()).backward()
-    grads = {k: p.grad.cpu() for k, p in net.named_parameters()}
-    return (y.detach().cpu(), xg.grad.cpu(), grads), ref(False), (ref(True) if emulate else ref(False, torch.float64) if exact else None)
+    (MSELoss()(y, t.cuda()) * loss_scale).backward()
+    grads = {k: p.grad.cpu() / loss_scale for k, p in net.named_parameters()}
+    return (y.detach().cpu(), xg.grad.cpu() / loss_scale, grads), ref(False), (ref(True) if emulate else ref(False, torch.float64) if exact else None)
 
 
 def test_rddbnet_nb23_f32_vs_oracle():
@@ -171,6 +173,24 @@ def test_rddbnet_nb23_bf16_vs_oracle():
     assert max(rel_l2(g[k], gr[k]) for k in g) < bound(fmt[0][0])
     med = sorted(rel_l2(g[k], gr[k]) for k in g)[len(g) // 2]
     assert med < bound(fmt[len(fmt) // 2][0]) and med < 3e-2
+
+
+def test_rddbnet_nb23_fp16_vs_oracle():
+    """The fp16 bench line's combination (BASELINE configs[4] --dtype fp16: nb = 23, IEEE half storage, f16 MFMA, trunk weights at
+    0.1 x the reference's initial scale, loss scale 1024) at bench depth, gated like the bf16 case: against the f32 oracle the native
+    error may not exceed 1.5 x that of the oracle with fp16 STORAGE (+ 0.5 %).  With the 0.1 x trunk the 345 layers do not amplify
+    and fp16's 11-bit significand keeps every figure well below the bf16 ones (printed: pytest -s)."""
+    (y, dx, g), (yr, dxr, gr), (ye, dxe, ge) = _rddbnet_depth_case("fp16", emulate=True, store_dtype=torch.float16, trunk_scale=0.1, loss_scale=1024.0)
+    assert all(torch.isfinite(v).all() for v in g.values()) and torch.isfinite(y).all() and torch.isfinite(dx).all()
+    errs = sorted(((rel_l2(g[k], gr[k]), k) for k in g), reverse=True)
+    fmt = sorted(((rel_l2(ge[k], gr[k]), k) for k in g), reverse=True)
+    print(f"nb=23 fp16 vs f32 oracle: y {rel_l2(y, yr):.5f} dx {rel_l2(dx, dxr):.5f} worst grads {errs[:3]} median {errs[len(errs) // 2][0]:.5f}")
+    print(f"   format alone (fp16-storage oracle vs f32 oracle): y {rel_l2(ye, yr):.5f} dx {rel_l2(dxe, dxr):.5f} worst {fmt[:2]} median {fmt[len(fmt) // 2][0]:.5f}")
+    bound = lambda e: 1.5 * e + 5e-3
+    assert rel_l2(y, yr) < bound(rel_l2(ye, yr)) and rel_l2(y, yr) < 1e-2
+    assert rel_l2(dx, dxr) < bound(rel_l2(dxe, dxr))
+    assert errs[0][0] < bound(fmt[0][0])
+    assert errs[len(errs) // 2][0] < bound(fmt[len(fmt) // 2][0]) and errs[len(errs) // 2][0] < 1e-2
 
 
 @pytest.mark.parametrize("tag", ["nlayerd_3", "nlayerd_2"])
