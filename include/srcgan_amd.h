@@ -168,6 +168,8 @@ int srcgan_wgrad_dense(const srcgan_wgrad_dense_desc* d, void* stream);
  *   mode 0: out0[c] = scale * sum a[p,c]                         (bias grad; BN mean)
  *   mode 1: out0[c] = scale * sum (a[p,c]-m[c])^2                (BN variance)
  *   mode 2: out0[c] = sum g[p,c] ; out1[c] = sum g[p,c]*(z[p,c]-m[c])*rstd[c]   (BN backward)
+ *   mode 3: out0[c] = mean of a[p,c] ; out1[c] = its biased variance -- ONE pass over a (per-thread shifted sums, partials
+ *           combined exactly in a fixed order); `scale` and `m` are not used                       (BN statistics, training)
  * scratch: 2*nblk*C floats, nblk = srcgan_col_reduce_blocks(npix).
  * ------------------------------------------------------------------------- */
 int srcgan_col_reduce_blocks(long npix);

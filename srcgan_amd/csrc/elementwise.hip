@@ -571,6 +571,102 @@ __global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ 
     }
 }
 
+// Mean and variance in ONE pass over the tensor (BatchNorm statistics; mode 3 of srcgan_col_reduce).  The two-pass form (mean, then
+// sum of squared deviations) read the convolution's output twice.  Here a thread keeps  S1 = sum (v - s), S2 = sum (v - s)^2  around
+// a shift s = ITS OWN first sample, which is within a few standard deviations of the mean whatever the mean is: no cancellation in
+// M2 = S2 - S1^2 / n.  Partials (n, mean, M2) are combined exactly (Chan et al.: M2 = M2a + M2b + d^2 na nb / (na + nb)) in a
+// fixed order: threads of a block by pixel lane, blocks by index -- deterministic.  partial[blk][c] = mean, partial[nblk + blk][c] = M2;
+// a block's count follows from (blk, npix, nblk).
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb <= 0.f) return;
+    const float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col_meanvar_vec_k(const T* __restrict__ a, int aCs, int acoff, long npix, int C, float* __restrict__ partial) {
+    constexpr int EPP = DT<T>::EPP;
+    typedef __attribute__((ext_vector_type(EPP))) T vecT;
+    __shared__ float red[2][256 * EPP];
+    __shared__ float cnt[256];
+    const int G = C / EPP, PL = 256 / G;
+    const int cg = threadIdx.x % G, pl = threadIdx.x / G, c0 = cg * EPP;
+    const long per = cdivl(npix, gridDim.x);
+    const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    float s1[EPP], s2[EPP], sh[EPP];
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) { s1[i] = 0.f; s2[i] = 0.f; sh[i] = 0.f; }
+    long px = p0 + pl;
+    float n = 0.f;
+    if (px < p1) {
+        const vecT av = *(const vecT*)(a + (size_t)px * aCs + acoff + c0);
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) sh[i] = to_f(av[i]);
+    }
+    auto acc1 = [&](const vecT& av) {
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) { const float d = to_f(av[i]) - sh[i]; s1[i] += d; s2[i] += d * d; }
+    };
+    for (; px + 3 * (long)PL < p1; px += 4 * (long)PL) {          // four pixels' loads in flight, additions in pixel order
+        vecT av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = *(const vecT*)(a + (size_t)(px + u * (long)PL) * aCs + acoff + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc1(av[u]);
+        n += 4.f;
+    }
+    for (; px < p1; px += PL) { acc1(*(const vecT*)(a + (size_t)px * aCs + acoff + c0)); n += 1.f; }
+    const float inv = n > 0.f ? 1.f / n : 0.f;
+#pragma unroll
+    for (int i = 0; i < EPP; ++i) {
+        red[0][threadIdx.x * EPP + i] = sh[i] + s1[i] * inv;                  // thread mean
+        red[1][threadIdx.x * EPP + i] = s2[i] - s1[i] * s1[i] * inv;          // thread M2
+    }
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float nn = 0.f, mean = 0.f, m2 = 0.f;
+        for (int q = 0; q < PL; ++q) {
+            const int t = q * G + c / EPP;
+            chan_combine(nn, mean, m2, cnt[t], red[0][t * EPP + c % EPP], red[1][t * EPP + c % EPP]);
+        }
+        partial[(size_t)blockIdx.x * C + c] = mean;
+        partial[((size_t)gridDim.x + blockIdx.x) * C + c] = m2;
+    }
+}
+// one block per 8 channels; 32 block-lanes each combine every 32nd block's partial (loads issued 4 at a time), then one thread per
+// channel combines the 32 lane results in lane order: a fixed order, and no 512-long chain of dependent loads and divisions
+// (one thread per channel over all blocks took 200 us)
+__global__ __launch_bounds__(256) void col_meanvar_finalize_k(const float* __restrict__ partial, int nblk, int C, long npix,
+                                                              float* __restrict__ mean_out, float* __restrict__ var_out) {
+    __shared__ float red[3][32][8];
+    const int cx = threadIdx.x & 7, py = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
+    const long per = cdivl(npix, (long)nblk);
+    auto count = [&](int b) { const long p0 = (long)b * per, p1 = (p0 + per < npix) ? p0 + per : npix; return p1 > p0 ? (float)(p1 - p0) : 0.f; };
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C) {
+        int b = py;
+        for (; b + 96 < nblk; b += 128) {
+            float mb[4], qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { mb[u] = partial[(size_t)(b + 32 * u) * C + c]; qb[u] = partial[((size_t)nblk + b + 32 * u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chan_combine(n, mean, m2, count(b + 32 * u), mb[u], qb[u]);
+        }
+        for (; b < nblk; b += 32) chan_combine(n, mean, m2, count(b), partial[(size_t)b * C + c], partial[((size_t)nblk + b) * C + c]);
+    }
+    red[0][py][cx] = n; red[1][py][cx] = mean; red[2][py][cx] = m2;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        float nn = 0.f, mm = 0.f, qq = 0.f;
+        for (int q = 0; q < 32; ++q) chan_combine(nn, mm, qq, red[0][q][cx], red[1][q][cx], red[2][q][cx]);
+        mean_out[c] = mm;
+        var_out[c] = qq / (float)npix;
+    }
+}
+
 extern "C" int srcgan_col_reduce_blocks(long npix) {
     long b = cdivl(npix, 256);
     return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
@@ -580,14 +676,26 @@ extern "C" int srcgan_col_reduce(int mode, const void* a, int a_cs, int a_coff, 
                                  const float* m, const float* rstd, long npix, int C, float scale,
                                  float* out0, float* out1, float* scratch, int dtype, void* stream) {
     SG_REQUIRE(a && out0 && scratch && npix > 0 && C > 0, "srcgan_col_reduce: bad arguments");
-    SG_REQUIRE(mode >= 0 && mode <= 2, "srcgan_col_reduce: bad mode %d", mode);
-    SG_REQUIRE(mode == 0 || m, "srcgan_col_reduce: mode %d needs mean", mode);
+    SG_REQUIRE(mode >= 0 && mode <= 3, "srcgan_col_reduce: bad mode %d", mode);
+    SG_REQUIRE(mode == 0 || mode == 3 || m, "srcgan_col_reduce: mode %d needs mean", mode);
     SG_REQUIRE(mode != 2 || (z && rstd && out1), "srcgan_col_reduce: mode 2 needs z, rstd, out1");
+    SG_REQUIRE(mode != 3 || out1, "srcgan_col_reduce: mode 3 needs out1 (variance)");
     const int nblk = srcgan_col_reduce_blocks(npix);
     hipStream_t st = (hipStream_t)stream;
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     const bool vec = C % epp == 0 && 256 % (C / epp) == 0 && a_cs % epp == 0 && a_coff % epp == 0 && ((uintptr_t)a % 16) == 0 &&
                      (mode != 2 || (z_cs % epp == 0 && z_coff % epp == 0 && ((uintptr_t)z % 16) == 0));
+    if (mode == 3) {        // mean (out0) and biased variance (out1) of every channel; `scale` is not used
+        if (!vec) {         // odd channel counts: the two-pass form
+            SG_TRY(srcgan_col_reduce(0, a, a_cs, a_coff, nullptr, 0, 0, nullptr, nullptr, npix, C, 1.f / (float)npix, out0, nullptr, scratch, dtype, stream));
+            return srcgan_col_reduce(1, a, a_cs, a_coff, nullptr, 0, 0, out0, nullptr, npix, C, 1.f / (float)npix, out1, nullptr, scratch, dtype, stream);
+        }
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(col_meanvar_vec_k<T>, dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, npix, C, scratch));
+        SG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(col_meanvar_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, st, scratch, nblk, C, npix, out0, out1);
+        SG_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec) {
         DISPATCH_DTYPE(dtype, {
             if (mode == 0) hipLaunchKernelGGL((col_reduce_vec_k<T, 0>), dim3(nblk), dim3(256), 0, st, (const T*)a, a_cs, a_coff, (const T*)z, z_cs, z_coff, m, rstd, npix, C, scratch);

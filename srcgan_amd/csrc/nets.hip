@@ -875,8 +875,7 @@ extern "C" int srcgan_nlayerd_forward_ex(const srcgan_nlayerd_cfg* c, const floa
             const float* gamma = params[P.pg[l]]; const float* beta = params[P.pbeta[l]];
             if (c->training) {
                 float* scr = (float*)(w8 + P.colscr);
-                SG_TRY(srcgan_col_reduce(0, z.p, cout, 0, nullptr, 0, 0, nullptr, nullptr, npix, cout, 1.f / (float)npix, mean, nullptr, scr, dt, st));
-                SG_TRY(srcgan_col_reduce(1, z.p, cout, 0, nullptr, 0, 0, mean, nullptr, npix, cout, 1.f / (float)npix, var, nullptr, scr, dt, st));
+                SG_TRY(srcgan_col_reduce(3, z.p, cout, 0, nullptr, 0, 0, nullptr, nullptr, npix, cout, 1.f, mean, var, scr, dt, st));      // one pass: mean and variance
                 SG_TRY(srcgan_bn_finalize(mean, var, rstd, bn_running ? bn_running[2 * bi] : nullptr, bn_running ? bn_running[2 * bi + 1] : nullptr,
                                           bn_nbt ? bn_nbt[bi] : nullptr, cout, npix, 0.1f, 1e-5f, st));
                 SG_TRY(srcgan_bn_apply_lrelu(z.p, y.p, mean, rstd, gamma, beta, npix, cout, cout, 0.2f, dt, st));

@@ -552,3 +552,29 @@ def test_stride2_input_gradient_all_parities_in_one_launch(ops, dt, cin, cout, h
     with pytest.raises(RuntimeError):            # odd channel count: refused, the caller keeps the four launches
         ops.conv_igemm(dyd, wall, torch.zeros(B, H, W, 3, device="cuda", dtype=dyd.dtype), kh=2, kw=2, Cout=3, OH=(H + 1) // 2, OW=(W + 1) // 2, os=2,
                        npar=4, wpar_stride=stride)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_single_pass_mean_and_variance(dt):
+    """BatchNorm statistics in one pass over the tensor (srcgan_col_reduce mode 3: per-thread shifted sums, partials combined by
+    Chan's formula in a fixed order) against float64: the variance to 1e-5 relative -- also where the mean is 250 standard
+    deviations from zero, the case a plain sum / sum-of-squares loses (the reference's native_batch_norm is a Welford form,
+    model/model.py:622-631) --, the mean to 1e-4 of a standard deviation (plus the input format's own resolution of the mean)."""
+    from srcgan_amd import _native as N
+    lib = N.lib()
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    torch.manual_seed(5)
+    for npix, C, mu, sd in ((100003, 128, 0.3, 1.0), (4097, 64, 1000.0, 4.0), (7, 256, -2.0, 0.5), (16 * 128 * 128, 256, 0.1, 2.0)):
+        a = (torch.randn(npix, C, device="cuda") * sd + mu).to(tdt)
+        mean, var = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        scr = torch.empty(2 * lib.srcgan_col_reduce_blocks(npix) * C, dtype=torch.float32, device="cuda")
+        N.check(lib.srcgan_col_reduce(3, a.data_ptr(), C, 0, None, 0, 0, None, None, npix, C, 1.0, mean.data_ptr(), var.data_ptr(),
+                                      scr.data_ptr(), N.dtype_id(a.dtype), N.stream_ptr(a.device)), "srcgan_col_reduce")
+        ad = a.double()
+        rm, rv = ad.mean(0), ad.var(0, unbiased=False)
+        assert float(((var.double() - rv).abs() / rv).max()) < 1e-5, (npix, C, mu)
+        assert float(((mean.double() - rm).abs() / rv.sqrt()).max()) < 1e-4 + abs(mu) * 2.0 ** -22 / sd, (npix, C, mu)
+        mean2, var2 = torch.empty_like(mean), torch.empty_like(var)             # deterministic: a second call gives the same bits
+        N.check(lib.srcgan_col_reduce(3, a.data_ptr(), C, 0, None, 0, 0, None, None, npix, C, 1.0, mean2.data_ptr(), var2.data_ptr(),
+                                      scr.data_ptr(), N.dtype_id(a.dtype), N.stream_ptr(a.device)), "srcgan_col_reduce")
+        assert torch.equal(mean, mean2) and torch.equal(var, var2)
