@@ -76,10 +76,12 @@ def test_paired_srgan_trajectories_agree_across_dtypes():
     assert ref["L1"][-1] < 0.8 * ref["L1"][0], ("the network must actually learn on this data", ref["L1"][0], ref["L1"][-1])
     # measured (round 3): bf16 L1 3.1 % / GAN 3.4 % / D 2.8 %, PSNR 15.04 -> 14.95 dB; fp16 3.7 / 4.3 / 4.0 %, 14.99 dB: both finish on the
     # fp32 curve (L1 0.1415 vs 0.1411 / 0.1405); the mid-curve deviation is the sensitivity of a 30-step GAN trajectory, not precision
-    # (fp16, with 3 more mantissa bits, deviates no less than bf16).  How sensitive: a later build whose fp16 epilogue rounds a few
-    # elements per 10^5 differently by one ulp (v_fma_mixlo_f16 instead of multiply + convert; bf16 bit-identical) ends at L1 0.1507 /
-    # 14.73 dB instead of 0.1405 / 14.99 dB with the curves no further from fp32 than before (3.7 / 3.4 / 2.6 %).  Bounds = 2 x measured.
-    for dt, bound_l1, bound_gan, bound_db in (("bf16", 0.06, 0.10, 0.3), ("fp16", 0.07, 0.10, 0.6)):
+    # (fp16, with 3 more mantissa bits, deviates no less than bf16).  How sensitive the END POINT is, seen on later builds: an fp16
+    # epilogue that rounds a few elements per 10^5 differently by one ulp (bf16 bit-identical) ended at L1 0.1507 / 14.73 dB instead of
+    # 0.1405 / 14.99 dB; BatchNorm statistics computed in one pass instead of two (a 1e-7 relative change) moved the fp32 run itself
+    # from 15.041 to 15.029 dB and the bf16 run to 14.52 dB -- while its curves came CLOSER to fp32 (1.0 / 1.4 / 1.4 %).  The final
+    # PSNR of one seed is therefore gated at 1 dB only; the curves carry the comparison.  Bounds on them = 2 x the largest measured.
+    for dt, bound_l1, bound_gan, bound_db in (("bf16", 0.06, 0.10, 1.0), ("fp16", 0.07, 0.10, 1.0)):
         cur, p = _paired(dt)
         d = {k: _dev(cur[k], ref[k]) for k in ref}
         print(f"paired {dt}: curve deviation from fp32 (relative to the curve's maximum) L1 {d['L1']:.4f} G_GAN {d['G_GAN']:.4f} D {d['D']:.4f}; "
