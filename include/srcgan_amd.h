@@ -110,7 +110,9 @@ typedef struct srcgan_conv_desc {
      * ONE launch.  x = dy [B,H,W,Cin = the layer's Cout], y = dx [B,YH,YW,..] (Cout = the layer's Cin), kh = kw = 2, stride = 1:
      *   dx[2t+a][2u+b] = sum_{ty,tx in {0,1}} dy[t+a-1+ty][u+b-1+tx] * pack_q[tap (ty,tx)],   q = 2a + b,
      * pack_q = wp + q * wpar_stride bytes (rows = the layer's Cin, k = its Cout, taps ky = (a?2:3) - 2ty, kx = (b?2:3) - 2tx).
-     * OH / OW / pad / os / oa / ob are derived from YH, YW; epilogue operands (mz, r1, ...) are indexed like y.  npar == 0: plain. */
+     * OH / OW / pad / os / oa / ob are derived from YH, YW; epilogue operands (mz, r1, ...) are indexed like y.  npar == 0: plain.
+     * npar == 4 with kh = kw = 1 (ConvTranspose2d k2 s2 as four 1x1 convolutions, rddb.py:28-38, in one launch): os = 2, oa = ob = 0;
+     *   y[2oy+a][2ox+b] = epilogue(x[oy][ox] * pack_q),  q = 2a + b,  pack_q = wp + q * wpar_stride bytes (Cout rows each). */
     int npar; long wpar_stride;
 } srcgan_conv_desc;
 int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream);

@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
         L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     }
-    const int ct = L % p.ctiles;
+    // npar == 4 (ConvTranspose2d k2 s2 as four 1x1 convolutions, rddb.py:28-38, in ONE launch): the ctiles channel tiles are
+    // (parity, tile within the parity); the four parities of a spatial tile are consecutive blocks of one XCD, so the input
+    // tile comes from HBM once and from that L2 three times (four launches read the input four times)
+    int ct = L % p.ctiles, par = 0;
+    if (p.npar) { const int cpp = p.ctiles / p.npar; par = ct / cpp; ct -= par * cpp; }
     int t = L / p.ctiles;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
             for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
     const char* xb = (const char*)p.x + (size_t)b * p.H * p.W * p.xpix + (size_t)p.xcoff * sizeof(T);
-    const char* wb = (const char*)p.wp + (size_t)ct * p.nchunk * NTAP * COT * 64;
+    const char* wb = (const char*)p.wp + (size_t)par * p.wpar + (size_t)ct * p.nchunk * NTAP * COT * 64;
 
     // ---- per-thread staging descriptors (independent of the channel chunk).  Loads are issued
     // unconditionally from a clamped address and zeroed by a select afterwards: no branches, so the
@@ -277,13 +281,15 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         if (keep == 1.2345e-30f) *(float*)p.y = keep;
         return;
     }
+    ConvP pe = p;
+    if (p.npar) { pe.oa = par >> 1; pe.ob = par & 1; }
     if (p.buf16) {
         constexpr int RS = COT * 4 + 16;
         char* lw = smem + wave * 32 * RS;
 #pragma unroll
-        for (int q = 0; q < PT; ++q) conv_epilogue_lds_row<T, MT, PT>(p, acc, q, lw, b, ct, oy0 + wave * PT + q, ox0, lane);
+        for (int q = 0; q < PT; ++q) conv_epilogue_lds_row<T, MT, PT>(pe, acc, q, lw, b, ct, oy0 + wave * PT + q, ox0, lane);
     } else
-        conv_epilogue<T, MT, PT>(p, acc, b, ct, oy0 + wave * PT, ox0, r, h);
+        conv_epilogue<T, MT, PT>(pe, acc, b, ct, oy0 + wave * PT, ox0, r, h);
 }
 
 // ------------------------------------------------------------------ host launcher
@@ -309,7 +315,7 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     char cls[96];
     snprintf(cls, sizeof(cls), "conv_igemm<%s,%dx%d,s%d,MT%d>", sizeof(T) == 4 ? "f32" : (__is_same(T, __bf16) ? "bf16" : "f16"), KH, KW, S, MT);
     // algorithmic work: 2*pixels*taps*Cin*Cout flop; bytes: input read once + output written once
-    const double px = (double)p.B * p.OH * p.OW;
+    const double px = (double)p.B * p.OH * p.OW * (p.npar ? p.npar : 1);
     const int tok = sg_prof_start(cls, 2.0 * px * NTAP * p.Cin * p.Cout,
                                   ((double)p.B * p.H * p.W * p.Cin + px * p.Cout) * sizeof(T), st);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, q);
@@ -405,7 +411,12 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
                   (!d->r2 || (p.r2plane < lim && p.r2pix < (1 << 20))) && (!d->mz || (p.mzplane < lim && p.mzpix < (1 << 20)));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->npar) {
+    if (d->npar && d->kh == 1 && d->kw == 1) {
+        // four output parities of a stride-2 scatter in one launch: parity q = (oa, ob) = (q >> 1, q & 1) uses the pack at wp + q * wpar_stride
+        SG_REQUIRE(d->npar == 4 && d->stride == 1 && d->os == 2 && d->oa == 0 && d->ob == 0 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 &&
+                   !d->sign_in && !d->sign_out, "srcgan_conv_igemm: npar == 4 with a 1x1 kernel needs os == 2, oa == ob == 0 and the four packs wpar_stride bytes apart");
+        p.npar = 4; p.wpar = d->wpar_stride;
+    } else if (d->npar) {
         SG_REQUIRE(d->npar == 4 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 && !d->x_plane && !d->y_plane &&
                    !d->sign_in && !d->sign_out && !d->bias,
                    "srcgan_conv_igemm: npar must be 0 or 4 (2x2 stride-1 parity packs wpar_stride bytes apart, interleaved tensors, no bias / sign masks)");
@@ -414,17 +425,18 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     }
     if (d->kh == 3 && d->kw == 3 && d->stride == 1 && (!g_force_generic || d->x_plane)) return sg_conv3x3_dma(p, d->dtype, st);
     // Cout <= 32 -> one 32-row M tile per workgroup, otherwise 64-row tiles.
+    const int npm = p.npar ? p.npar : 1;        // channel tiles = parities x tiles of one parity
     if (d->Cout <= 32) {
-        if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, 1, st);
-        if (d->dtype == SRCGAN_F16) return dispatch_shape<_Float16, 1>(p, d->kh, d->kw, d->stride, 1, st);
-        return dispatch_shape<__bf16, 1>(p, d->kh, d->kw, d->stride, 1, st);
+        if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 1>(p, d->kh, d->kw, d->stride, npm, st);
+        if (d->dtype == SRCGAN_F16) return dispatch_shape<_Float16, 1>(p, d->kh, d->kw, d->stride, npm, st);
+        return dispatch_shape<__bf16, 1>(p, d->kh, d->kw, d->stride, npm, st);
     }
 #ifdef SG_MT4_22
     // (variant) stride-2 parity gradients with >= 128 output rows: one 128-row tile per workgroup halves the dy staging per FLOP
     if (d->dtype == SRCGAN_BF16 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->Cout % 128 == 0)       // (the variant instantiates bf16 only)
         return launch_igemm<__bf16, 2, 2, 1, 4, SG_PT22, false>(p, d->Cout / 128, st);
 #endif
-    const int ctiles = cdiv(d->Cout, 64);
+    const int ctiles = cdiv(d->Cout, 64) * npm;
     if (d->dtype == SRCGAN_F32) return dispatch_shape<float, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
     if (d->dtype == SRCGAN_F16) return dispatch_shape<_Float16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);
     return dispatch_shape<__bf16, 2>(p, d->kh, d->kw, d->stride, ctiles, st);

@@ -19,7 +19,8 @@ struct ConvP {
     int vec16;    // every epilogue tensor allows 16-byte accesses per lane (LDS-transposed epilogue)
     int buf16;    // vec16, and every epilogue tensor's channel plane is below 2 GiB: the row epilogue's 32-bit buffer offsets (conv_epilogue_lds_row)
     int rev;      // images are walked last to first
-    long wpar;    // dgrad_s2k4 (conv_par4.hip): bytes between the packs of consecutive output parities
+    long wpar;    // dgrad_s2k4 (conv_par4.hip) and the four-parity 1x1 form: bytes between the packs of consecutive output parities
+    int npar;     // conv_igemm_k: 4 = the channel-tile index also selects an output parity (oa, ob) = (par >> 1, par & 1) and its weight pack
     unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null

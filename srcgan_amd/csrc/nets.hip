@@ -425,6 +425,14 @@ extern "C" int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const floa
     // up-sampler: ConvTranspose2d(k2,s2) + LeakyReLU == 4 x (1x1 conv -> stride-2 scatter) (rddb.py:93-97,111-112)
     for (int s = 0; s < P.nst; ++s) {
         const int h = H << s, w = W << s;
+        const long wstep = (long)(P.w_up_f[s][1] - P.w_up_f[s][0]);
+        if (P.w_up_f[s][2] == P.w_up_f[s][0] + 2 * (size_t)wstep && P.w_up_f[s][3] == P.w_up_f[s][0] + 3 * (size_t)wstep && wstep > 0) {
+            // all four output parities in one launch (the input is read from HBM once: conv_igemm.hip, npar)
+            Conv cv(dt, 1, 1, 1);
+            cv.in(T_(P.U[s], nf), B, h, w, nf).w(wp + P.w_up_f[s][0]).out(T_(P.U[s + 1], nf), h, w, nf).scatter(2, 0, 0, 2 * h, 2 * w).lrelu();
+            cv.d.npar = 4; cv.d.wpar_stride = wstep;
+            SG_TRY(cv.run(st));
+        } else
         for (int q = 0; q < 4; ++q)
             SG_TRY(Conv(dt, 1, 1, 1).in(T_(P.U[s], nf), B, h, w, nf).w(wp + P.w_up_f[s][q]).out(T_(P.U[s + 1], nf), h, w, nf)
                        .scatter(2, q >> 1, q & 1, 2 * h, 2 * w).lrelu().run(st));

@@ -578,3 +578,23 @@ def test_single_pass_mean_and_variance(dt):
         N.check(lib.srcgan_col_reduce(3, a.data_ptr(), C, 0, None, 0, 0, None, None, npix, C, 1.0, mean2.data_ptr(), var2.data_ptr(),
                                       scr.data_ptr(), N.dtype_id(a.dtype), N.stream_ptr(a.device)), "srcgan_col_reduce")
         assert torch.equal(mean, mean2) and torch.equal(var, var2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_deconv_k2s2_all_parities_in_one_launch(ops, dt):
+    """The four 1x1 parity convolutions of ConvTranspose2d(k2, s2) + LeakyReLU (rddb.py:28-38) as ONE launch (npar = 4, kh = kw = 1):
+    bit-identical to the four launches, on a ragged size."""
+    torch.manual_seed(14)
+    x = torch.rand(2, 64, 9, 37) - 0.5
+    w = torch.randn(64, 64, 2, 2) * 0.1      # [cin, cout, 2, 2]
+    xd = _nhwc(ops, x, 64, dt)
+    packs = [ops.pack_weight(w.cuda(), 64, 64, 1, 1, 4, 64 * 4, 0, 0, q, dt) for q in range(4)]
+    y4 = torch.zeros(2, 18, 74, 64, dtype=xd.dtype, device="cuda")
+    for q in range(4):
+        ops.conv_igemm(xd, packs[q], y4, kh=1, kw=1, Cout=64, OH=9, OW=37, act=True, os=2, oa=q >> 1, ob=q & 1)
+    allp = torch.cat([pk.reshape(-1) for pk in packs])
+    y1 = torch.zeros_like(y4)
+    ops.conv_igemm(xd, allp, y1, kh=1, kw=1, Cout=64, OH=9, OW=37, act=True, os=2, oa=0, ob=0, npar=4, wpar_stride=packs[0].numel() * packs[0].element_size())
+    assert torch.equal(y1, y4)
+    ref = F.leaky_relu(F.conv_transpose2d(_q(x, dt), _q(w, dt), None, 2, 0), 0.2)
+    assert rel_err(ops.to_nchw(y1).cpu(), ref) < TOL[dt]
