@@ -208,7 +208,9 @@ int srcgan_add_inplace_planes(void* y, int y_cs, int y_coff, long y_plane, const
  * (written by forward, read by backward).  backward: g = dy [* (yact > 0)] (yact = the forward output when ReLU was applied);
  * dx = GroupNorm backward of g; dres (optional) = g (gradient of the residual branch; += when dres_accumulate); dgamma / dbeta
  * (optional) f32 [C], += when accumulate (a GroupNorm module applied twice, edsr.py:41,47,49).
- * scratch: srcgan_gn_scratch_floats(B, C) floats.  C/epp must divide 256 (epp = 16 bytes of channels). */
+ * scratch: srcgan_gn_scratch_floats(B, C) floats.  C/epp must divide 256 (epp = 16 bytes of channels).
+ * gamma and / or beta may be null: no affine part -- with G == C that is nn.InstanceNorm2d(C) (model/model.py:598-631 with
+ * norm_layer = InstanceNorm2d, basicModel.py:24-25). */
 size_t srcgan_gn_scratch_floats(int B, int C);
 int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void* y, int y_cs, const float* gamma, const float* beta,
                       float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream);
@@ -311,12 +313,16 @@ int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const float* dy_nchw
 
 /* NLayerDiscriminator (model/model.py:595-639).  params in state_dict order of the
  * learnable tensors: conv0.w, conv0.b, [conv_l.w, bn_l.gamma, bn_l.beta]*, conv_last.w, conv_last.b.
- * bn_state: per BN layer running_mean, running_var (f32) ; nbt: int64 counters. */
+ * bn_state: per BN layer running_mean, running_var (f32) ; nbt: int64 counters.
+ * norm = 1: norm_layer = nn.InstanceNorm2d (model/model.py:607-610: the normalised convolutions then HAVE a bias; InstanceNorm2d
+ * as basicModel.py:24-25 builds it -- no affine parameters, no running statistics, instance statistics in train and eval mode):
+ * learnable tensors conv0.w, conv0.b, [conv_l.w, conv_l.b]*, conv_last.w, conv_last.b; bn_running / bn_nbt are not read. */
 typedef struct srcgan_nlayerd_cfg {
     int in_ch, ndf, n_layers;
     int B, H, W;
     int dtype;
     int training;
+    int norm;              /* 0 = BatchNorm2d (the reference's default), 1 = InstanceNorm2d */
 } srcgan_nlayerd_cfg;
 int srcgan_nlayerd_num_params(const srcgan_nlayerd_cfg* c);
 int srcgan_nlayerd_out_hw(const srcgan_nlayerd_cfg* c, int* oh, int* ow);

@@ -349,19 +349,21 @@ def _d_plan(n_layers: int) -> List[Tuple[int, int, bool, bool]]:
     return plan
 
 
-def nlayer_d_keys(n_layers: int) -> List[str]:
+def nlayer_d_keys(n_layers: int, norm: str = "batch") -> List[str]:
     keys: List[str] = []
     for (i, _s, has_bias, bn) in _d_plan(n_layers):
         keys.append(f"model.{i}.weight")
-        if has_bias:
+        if has_bias or (bn and norm == "instance"):
             keys.append(f"model.{i}.bias")
-        if bn:
+        if bn and norm == "batch":
             keys += [f"model.{i + 1}.{n}" for n in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
     return keys
 
 
-def nlayer_d_state(input_nc: int, ndf: int = 64, n_layers: int = 3, seed: int = 0) -> State:
-    """torch-default init (the reference never re-initialises D)."""
+def nlayer_d_state(input_nc: int, ndf: int = 64, n_layers: int = 3, seed: int = 0, norm: str = "batch") -> State:
+    """torch-default init (the reference never re-initialises D).  norm = "instance": norm_layer = nn.InstanceNorm2d
+    (model/model.py:607-610: the normalised convolutions get a bias; InstanceNorm2d itself has no parameters or buffers,
+    basicModel.py:24-25)."""
     g = torch.Generator().manual_seed(seed)
     chans = [input_nc, ndf]
     for n in range(1, n_layers):
@@ -372,9 +374,9 @@ def nlayer_d_state(input_nc: int, ndf: int = 64, n_layers: int = 3, seed: int = 
     for li, (i, _s, has_bias, bn) in enumerate(_d_plan(n_layers)):
         ci, co = chans[li], chans[li + 1]
         sd[f"model.{i}.weight"] = _default_uniform((co, ci, 4, 4), ci * 16, g)
-        if has_bias:
+        if has_bias or (bn and norm == "instance"):
             sd[f"model.{i}.bias"] = _default_uniform((co,), ci * 16, g)
-        if bn:
+        if bn and norm == "batch":
             sd[f"model.{i + 1}.weight"] = torch.ones(co)
             sd[f"model.{i + 1}.bias"] = torch.zeros(co)
             sd[f"model.{i + 1}.running_mean"] = torch.zeros(co)
@@ -406,6 +408,12 @@ def nlayer_d_forward(sd: State, x: Tensor, training: bool = True) -> Tensor:
                 sd[f"model.{j}.num_batches_tracked"] += 1
             h = F.batch_norm(h, sd[f"model.{j}.running_mean"], sd[f"model.{j}.running_var"],
                              sd[f"model.{j}.weight"], sd[f"model.{j}.bias"], training, BN_MOMENTUM, BN_EPS)
+            h = _st(_lrelu(h))
+        elif i != conv_ids[0] and f"model.{i + 2}.weight" not in sd and f"model.{i + 3}.weight" in sd:
+            # norm_layer = InstanceNorm2d: (conv + bias, InstanceNorm2d, LeakyReLU) occupy three Sequential slots, no parameters in
+            # the middle one; instance statistics in train and eval mode (track_running_stats=False)
+            h = _st(h)
+            h = F.instance_norm(h, None, None, None, None, True, BN_MOMENTUM, BN_EPS)
             h = _st(_lrelu(h))
         else:                 # (no BatchNorm: conv + bias + LeakyReLU is ONE native store)
             h = _st(_lrelu(h))

@@ -100,7 +100,7 @@ class SrNetCfg(C.Structure):
 
 class NLayerDCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("ndf", C.c_int), ("n_layers", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int), ("training", C.c_int), ("norm", C.c_int)]
 
 
 # name -> (restype, argtypes).  Must list every symbol include/srcgan_amd.h declares

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_fold_k(const float* __restrict__ parti
     for (int c = threadIdx.x; c < C; c += 256) {
         float t0 = 0.f, t1 = 0.f;
         for (int k = 0; k < nblk; ++k) { const float* p = partial + (((size_t)b * nblk + k) * C + c) * 2; t0 += p[0]; t1 += p[1]; }
-        if (MODE == 1) { chan[((size_t)b * C + c) * 2] = t0; chan[((size_t)b * C + c) * 2 + 1] = t1; t0 *= gamma[c]; t1 *= gamma[c]; }
+        if (MODE == 1) { chan[((size_t)b * C + c) * 2] = t0; chan[((size_t)b * C + c) * 2 + 1] = t1; if (gamma) { t0 *= gamma[c]; t1 *= gamma[c]; } }
         cs[0][c] = t0; cs[1][c] = t1;
     }
     __syncthreads();
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gn_apply_k(const T* __restrict__ x, int x
         for (int i = 0; i < EPP; ++i) {
             const int c = c0 + i, g = c / cpg;
             const float mu = stats[(b * G + g) * 2], rs = stats[(b * G + g) * 2 + 1];
-            float v = (to_f(xv[i]) - mu) * rs * gamma[c] + beta[c];
+            float v = (to_f(xv[i]) - mu) * rs * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);      // null gamma / beta: no affine part (InstanceNorm2d)
             if (res) v += to_f(rv[i]);
             if (relu) v = v > 0.f ? v : v * slope;
             o[i] = from_f<T>(v);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const T* __restrict__ dy, 
             float gg = to_f(gv[i]);
             if (yact && !(to_f(av[i]) > 0.f)) gg *= slope;
             const float xh = (to_f(xv[i]) - mu) * rs;
-            o[i] = from_f<T>(rs * (gg * gamma[c] - (gsum[(b * G + g) * 2] + xh * gsum[(b * G + g) * 2 + 1])));
+            o[i] = from_f<T>(rs * (gg * (gamma ? gamma[c] : 1.f) - (gsum[(b * G + g) * 2] + xh * gsum[(b * G + g) * 2 + 1])));
             gm[i] = from_f<T>(gg);
         }
         *(vecT*)(dx + q * dx_cs + c0) = o;
@@ -186,7 +186,7 @@ extern "C" size_t srcgan_gn_scratch_floats(int B, int C) { return (size_t)B * GN
 
 extern "C" int srcgan_gn_forward(const void* x, int x_cs, const void* res, int res_cs, void* y, int y_cs, const float* gamma, const float* beta,
                                  float* stats, int B, long hw, int C, int G, float eps, int relu, float slope, int dtype, float* scratch, void* stream) {
-    SG_REQUIRE(x && y && gamma && beta && stats && scratch, "srcgan_gn_forward: null pointer");
+    SG_REQUIRE(x && y && stats && scratch, "srcgan_gn_forward: null pointer");
     SG_TRY(gn_check("srcgan_gn_forward", B, hw, C, G, dtype));
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(x_cs % epp == 0 && y_cs % epp == 0 && (!res || res_cs % epp == 0), "srcgan_gn_forward: channel strides must be multiples of %d", epp);
@@ -205,7 +205,7 @@ extern "C" int srcgan_gn_forward(const void* x, int x_cs, const void* res, int r
 extern "C" int srcgan_gn_backward(const void* dy, int dy_cs, const void* yact, int ya_cs, const void* x, int x_cs, const float* gamma, const float* stats,
                                   void* dx, int dx_cs, void* dres, int dres_cs, int dres_accumulate, float* dgamma, float* dbeta, int accumulate,
                                   float slope, int B, long hw, int C, int G, int dtype, float* scratch, void* stream) {
-    SG_REQUIRE(dy && x && gamma && stats && dx && scratch, "srcgan_gn_backward: null pointer");
+    SG_REQUIRE(dy && x && stats && dx && scratch, "srcgan_gn_backward: null pointer");
     SG_TRY(gn_check("srcgan_gn_backward", B, hw, C, G, dtype));
     const int epp = dtype == SRCGAN_F32 ? 4 : 8;
     SG_REQUIRE(dy_cs % epp == 0 && x_cs % epp == 0 && dx_cs % epp == 0 && (!yact || ya_cs % epp == 0) && (!dres || dres_cs % epp == 0),

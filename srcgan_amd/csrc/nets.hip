@@ -723,6 +723,9 @@ struct DPlan {
     size_t wf[8], wd[8][4];
     int pw[8], pb[8], pg[8], pbeta[8];   // parameter indices (-1 if absent)
     int bn_idx[8];                       // index among BN layers (-1 if none)
+    int inorm;                           // norm_layer = InstanceNorm2d: the normalised layers are GroupNorm(G = C) without affine part
+    int nrm[8];                          // layer l is followed by a normalisation layer
+    size_t gnscr;                        // GroupNorm scratch (instance norm)
     int s2d;                             // first layer in space-to-depth form (even H, W): 2x2 s1 over 32-channel blocks, K not padded
 };
 
@@ -733,6 +736,8 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     SG_REQUIRE(c->ndf > 0 && c->ndf % 8 == 0, "nlayerd: ndf must be a multiple of 8");
     SG_REQUIRE(c->n_layers >= 1 && c->n_layers <= 5, "nlayerd: n_layers must be in 1..5");
     SG_REQUIRE(c->B > 0 && c->H > 0 && c->W > 0, "nlayerd: bad B/H/W");
+    SG_REQUIRE(c->norm == 0 || c->norm == 1, "nlayerd: norm must be 0 (BatchNorm2d) or 1 (InstanceNorm2d)");
+    P.inorm = c->norm == 1;
     P.dtype = c->dtype; P.esz = c->dtype == SRCGAN_F32 ? 4 : 2;
     P.L = c->n_layers + 2;
     P.ch[0] = c->in_ch; P.ch[1] = c->ndf;
@@ -754,7 +759,8 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     P.xin = b.take(P.s2d ? B * (c->H / 2 + 1) * (c->W / 2 + 1) * 32 * e : B * c->H * c->W * P.in_cs * e);
     int n = 0, nbn = 0;
     for (int l = 0; l < P.L; ++l) {
-        const bool bn = (l >= 1 && l <= P.L - 2), bias = (l == 0 || l == P.L - 1);
+        const bool nrm = (l >= 1 && l <= P.L - 2), bn = nrm && !P.inorm, bias = (l == 0 || l == P.L - 1 || (nrm && P.inorm));
+        P.nrm[l] = nrm;
         P.pw[l] = n++;
         P.pb[l] = bias ? n++ : -1;
         P.pg[l] = bn ? n++ : -1;
@@ -764,10 +770,19 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
         if (l == P.L - 1) P.out = b.take(sz);
         else {
             P.Y[l] = b.take(sz);
-            if (bn) { P.Z[l] = b.take(sz); P.stat[l] = b.take((size_t)3 * P.ch[l + 1] * sizeof(float)); }
+            if (nrm) {      // BatchNorm: mean[C], var[C], rstd[C]; instance norm: {mean, rstd}[B][C]
+                P.Z[l] = b.take(sz);
+                P.stat[l] = b.take((P.inorm ? (size_t)2 * B * P.ch[l + 1] : (size_t)3 * P.ch[l + 1]) * sizeof(float));
+            }
         }
     }
     P.nparams = n;
+    P.gnscr = 0;
+    if (P.inorm) {
+        int cmax = 8; for (int l = 1; l < P.L; ++l) if (P.ch[l] > cmax) cmax = P.ch[l];
+        SG_REQUIRE(cmax <= 1024 && cmax % (16 / (int)e) == 0 && 256 % (cmax / (16 / (int)e)) == 0, "nlayerd: InstanceNorm2d needs channel counts that are powers of two up to 1024");
+        P.gnscr = b.take(srcgan_gn_scratch_floats(c->B, cmax) * sizeof(float));
+    }
     {
         int cmax = 8; for (int l = 1; l < P.L; ++l) if (P.ch[l] > cmax) cmax = P.ch[l];
         P.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks((long)B * P.hh[1] * P.ww[1]) * cmax * sizeof(float));
@@ -790,7 +805,7 @@ static int d_plan(const srcgan_nlayerd_cfg* c, DPlan& P) {
     return 0;
 }
 
-struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, gfold, total; };
+struct DBwdPlan { size_t dO, g[2], dxin, slab, colscr, sums, gfold, gnscr, total; };
 static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q) {
     const size_t e = P.esz, B = c->B;
     Bump b;
@@ -810,6 +825,7 @@ static void d_bwd_plan(const srcgan_nlayerd_cfg* c, const DPlan& P, DBwdPlan& Q)
     int cmax = 8; for (int l = 1; l <= P.L; ++l) if (P.ch[l] > cmax) cmax = P.ch[l];
     Q.colscr = b.take((size_t)2 * srcgan_col_reduce_blocks((long)B * P.hh[1] * P.ww[1]) * cmax * sizeof(float));
     Q.sums = b.take((size_t)2 * cmax * sizeof(float));
+    Q.gnscr = P.inorm ? b.take(srcgan_gn_scratch_floats(c->B, cmax) * sizeof(float)) : 0;
     Q.total = b.off + 256;
 }
 }  // namespace
@@ -878,6 +894,12 @@ extern "C" int srcgan_nlayerd_forward_ex(const srcgan_nlayerd_cfg* c, const floa
         } else {                            // conv -> BatchNorm2d -> LeakyReLU (model/model.py:620-631)
             TRef z = tref(w8 + P.Z[l], cout), y = tref(w8 + P.Y[l], cout);
             SG_TRY(cv.out(z, oh, ow, cout).run(st));
+            if (P.inorm) {                  // InstanceNorm2d (no affine part, instance statistics in either mode) + LeakyReLU
+                SG_TRY(srcgan_gn_forward(z.p, cout, nullptr, 0, y.p, cout, nullptr, nullptr, (float*)(w8 + P.stat[l]), B, (long)oh * ow, cout, cout,
+                                         1e-5f, 1, 0.2f, dt, (float*)(w8 + P.gnscr), st));
+                cur = y;
+                continue;
+            }
             float* mean = (float*)(w8 + P.stat[l]); float* var = mean + cout; float* rstd = var + cout;
             const int bi = P.bn_idx[l];
             const float* gamma = params[P.pg[l]]; const float* beta = params[P.pbeta[l]];
@@ -903,7 +925,7 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
                                           void* ws, void* scratch, float* const* grads, float* dx_nchw, const srcgan_net_opts* opt, void* st) {
     DPlan P;
     SG_TRY(d_plan(c, P));
-    SG_REQUIRE(c->training, "srcgan_nlayerd_backward: backward through eval-mode BatchNorm is not supported");
+    SG_REQUIRE(c->training || P.inorm, "srcgan_nlayerd_backward: backward through eval-mode BatchNorm is not supported");
     SG_REQUIRE(dy_nchw && params && ws && scratch && grads, "srcgan_nlayerd_backward: null pointer");
     DBwdPlan Q;
     d_bwd_plan(c, P, Q);
@@ -948,6 +970,12 @@ extern "C" int srcgan_nlayerd_backward_ex(const srcgan_nlayerd_cfg* c, const flo
         const int ih = P.hh[l], iw = P.ww[l], oh = P.hh[l + 1], ow = P.ww[l + 1];
         const long npix = (long)B * oh * ow;
         const bool bn = P.bn_idx[l] >= 0;
+        if (P.nrm[l] && P.inorm) {
+            // dcur = dL/dy * lrelu'(y) (mask fused in the producer); instance-norm backward per (image, channel), in place
+            TRef z = tref(w8 + P.Z[l], cout);
+            SG_TRY(srcgan_gn_backward(dcur.p, dcur.cs, nullptr, 0, z.p, cout, nullptr, (const float*)(w8 + P.stat[l]), dcur.p, dcur.cs, nullptr, 0, 0,
+                                      nullptr, nullptr, 0, 0.2f, B, (long)oh * ow, cout, cout, dt, (float*)(s8 + Q.gnscr), st));
+        }
         if (bn) {
             // dcur = dL/dy * lrelu'(y) (mask fused in the producer).  BN backward (train): needs sum g, sum g*xhat
             float* mean = (float*)(w8 + P.stat[l]); float* rstd = mean + 2 * cout;

@@ -663,18 +663,19 @@ class _NLayerDFn(torch.autograd.Function):
     def forward(ctx, x, cfg_items, running, nbt, *params):
         N.require_cuda(x, "NLayerDiscriminator.forward")
         lib = N.lib()
-        in_ch, ndf, n_layers, dtype, training, pstate = cfg_items
+        in_ch, ndf, n_layers, dtype, training, pstate = cfg_items[:6]
+        norm = cfg_items[6] if len(cfg_items) > 6 else 0
         if x.dim() != 4 or x.shape[1] != in_ch:
             raise ValueError(f"NLayerDiscriminator expects [B,{in_ch},H,W], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
         B, _, H, W = x.shape
-        cfg = N.NLayerDCfg(in_ch, ndf, n_layers, B, H, W, dtype, int(training))
+        cfg = N.NLayerDCfg(in_ch, ndf, n_layers, B, H, W, dtype, int(training), norm)
         plist = [p.detach().contiguous() for p in params]
         oh, ow = C.c_int(), C.c_int()
         N.check(lib.srcgan_nlayerd_out_hw(C.byref(cfg), C.byref(oh), C.byref(ow)), "srcgan_nlayerd_out_hw")
         ws = N.workspace(lib.srcgan_nlayerd_ws_bytes(C.byref(cfg)), x.device)
         y = torch.empty(B, 1, oh.value, ow.value, dtype=torch.float32, device=x.device)
-        layout = (in_ch, ndf, n_layers, dtype, H % 2, W % 2)          # (the first layer's packed form depends on the parity of H, W)
+        layout = (in_ch, ndf, n_layers, dtype, H % 2, W % 2, norm)    # (the first layer's packed form depends on the parity of H, W)
         opt = pstate.opts(lib.srcgan_nlayerd_wpack_bytes, cfg, plist, layout, False, x.device)
         N.check(lib.srcgan_nlayerd_forward_ex(C.byref(cfg), x.data_ptr(), N.ptr_array(plist), N.ptr_array(running),
                                               N.ptr_array(nbt), ws.data_ptr(), y.data_ptr(), C.byref(opt), N.stream_ptr(x.device)),
@@ -715,25 +716,42 @@ class NLayerDiscriminator(nn.Module):
     """PatchGAN discriminator, drop-in for reference ``model.model.NLayerDiscriminator``
     (model/model.py:595-639): conv4x4 s2 + LeakyReLU | (n-1) x [conv4x4 s2, BatchNorm2d, LeakyReLU] |
     conv4x4 s1, BN, LeakyReLU | conv4x4 s1 -> 1 channel.  BatchNorm uses per-replica batch statistics
-    in train mode and updates the running buffers like nn.BatchNorm2d."""
+    in train mode and updates the running buffers like nn.BatchNorm2d.
+
+    ``norm_layer`` as in the reference: ``nn.BatchNorm2d`` (default) or ``nn.InstanceNorm2d`` -- the class or the
+    ``functools.partial`` that ``basicModel.get_norm_layer`` builds (affine=False, track_running_stats=False); with InstanceNorm2d
+    the normalised convolutions have a bias (model/model.py:607-610) and the layers normalise every image by its own statistics in
+    train and eval mode."""
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, dtype=None):
         super().__init__()
+        nkw = {}
         if isinstance(norm_layer, functools.partial):
-            norm_layer = norm_layer.func
-        if norm_layer is not nn.BatchNorm2d:
-            raise NotImplementedError("native NLayerDiscriminator implements the BatchNorm2d variant the reference uses")
+            nkw, norm_layer = dict(norm_layer.keywords), norm_layer.func
+        if norm_layer is nn.InstanceNorm2d:
+            if nkw.get("affine", False) or nkw.get("track_running_stats", False):
+                raise NotImplementedError("native NLayerDiscriminator: InstanceNorm2d without affine parameters / running statistics "
+                                          "(what nn.InstanceNorm2d defaults to and basicModel.get_norm_layer('instance') builds)")
+            inorm = True
+        elif norm_layer is nn.BatchNorm2d:
+            if not nkw.get("affine", True) or not nkw.get("track_running_stats", True):
+                raise NotImplementedError("native NLayerDiscriminator: BatchNorm2d with affine parameters and running statistics")
+            inorm = False
+        else:
+            raise NotImplementedError("native NLayerDiscriminator implements norm_layer = nn.BatchNorm2d (the reference's default) or nn.InstanceNorm2d")
+        norm = (lambda c: nn.InstanceNorm2d(c)) if inorm else (lambda c: nn.BatchNorm2d(c))
         kw, padw = 4, 1
         seq = [nn.Conv2d(input_nc, ndf, kw, 2, padw), nn.LeakyReLU(0.2, True)]
         mult = 1
         for n in range(1, n_layers):
             prev, mult = mult, min(2 ** n, 8)
-            seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 2, padw, bias=False), nn.BatchNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+            seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 2, padw, bias=inorm), norm(ndf * mult), nn.LeakyReLU(0.2, True)]
         prev, mult = mult, min(2 ** n_layers, 8)
-        seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 1, padw, bias=False), nn.BatchNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 1, padw, bias=inorm), norm(ndf * mult), nn.LeakyReLU(0.2, True)]
         seq += [nn.Conv2d(ndf * mult, 1, kw, 1, padw)]
         self.model = nn.Sequential(*seq)
         self._cfg = (input_nc, ndf, n_layers)
+        self._norm = 1 if inorm else 0
         self.compute_dtype = N.dtype_name(dtype)
         self._pack = _PackState()
 
@@ -745,7 +763,7 @@ class NLayerDiscriminator(nn.Module):
         bns = [m for m in self.model if isinstance(m, nn.BatchNorm2d)]
         running = [t for m in bns for t in (m.running_mean, m.running_var)]
         nbt = [m.num_batches_tracked for m in bns]
-        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self.training, self._pack)
+        cfg = (*self._cfg, N.dtype_id(self.compute_dtype), self.training, self._pack, self._norm)
         return _NLayerDFn.apply(input, cfg, running, nbt, *self.parameters())
 
     def extra_repr(self):

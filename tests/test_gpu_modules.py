@@ -219,6 +219,92 @@ def test_nlayerd_golden_f32(tag):
         assert rel_err(net(x.detach()).cpu(), g["y_eval"]) < F32_TOL
 
 
+def test_nlayerd_instance_norm_golden_f32():
+    """norm_layer = nn.InstanceNorm2d against the REFERENCE's own run (tests/golden/nlayerd_in.npz): output, input gradient, every
+    parameter gradient (the normalised convolutions' biases included) and the eval-mode pass, which uses instance statistics too."""
+    from srcgan_amd import NLayerDiscriminator, GANLoss
+    g = load_golden("nlayerd_in")
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    net = _load(NLayerDiscriminator(ic, ndf, nl, norm_layer=torch.nn.InstanceNorm2d, dtype="fp32"), sub(g, "sd/"))
+    net.train()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.cpu(), g["y"]) < F32_TOL
+    loss = GANLoss("lsgan", device="cuda")(y, True)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < F32_TOL
+    grads = sub(g, "grad/")
+    wmax = max(float(v.abs().max()) for k, v in grads.items() if k.endswith("weight"))
+    for k, p in net.named_parameters():
+        if k.endswith("bias") and k not in ("model.0.bias", f"model.{3 * nl + 2}.bias"):
+            # a bias in front of InstanceNorm2d cancels in the normalisation: its gradient is exactly zero in exact arithmetic and
+            # rounding noise in the reference (1e-7 here) as in the native path
+            assert float(p.grad.abs().max()) < 1e-5 * wmax and float(grads[k].abs().max()) < 1e-5 * wmax, k
+        else:
+            assert rel_err(p.grad.cpu(), grads[k]) < F32_TOL, k
+    net.eval()
+    xe = x.detach().clone().requires_grad_(True)
+    ye = net(xe)
+    assert rel_err(ye.detach().cpu(), g["y_eval"]) < F32_TOL
+    ye.square().mean().backward()                   # instance statistics: the eval-mode pass is differentiable too
+    assert torch.isfinite(xe.grad).all()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_nlayerd_instance_norm_full_width_vs_oracle(dt):
+    """ndf = 64, 3 layers with InstanceNorm2d on a 3 x 96 x 128 batch and a frozen pass, against the CPU oracle.  16-bit modes: relative
+    L2 against the f32 oracle within 1.5 x the error of the oracle that merely STORES activations and weights in that format (+ 0.5 %)."""
+    from srcgan_amd import NLayerDiscriminator, GANLoss
+    from srcgan_amd.train import set_requires_grad
+    torch.manual_seed(0)
+    sd = oracle.nlayer_d_state(3, 64, 3, seed=4, norm="instance")
+    x = torch.rand(2, 3, 96, 128)
+
+    def ref(store):
+        rsd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        if store is None:
+            yr = oracle.nlayer_d_forward(rsd, xr, True)
+        else:
+            with oracle.storage(store):
+                yr = oracle.nlayer_d_forward(rsd, xr, True)
+        oracle.gan_loss(yr, True).backward()
+        return yr.detach(), xr.grad, {k: v.grad for k, v in rsd.items()}
+
+    yr, dxr, gr = ref(None)
+    net = _load(NLayerDiscriminator(3, 64, 3, norm_layer=torch.nn.InstanceNorm2d, dtype=dt), sd)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    GANLoss("lsgan", device="cuda")(y, True).backward()
+    wmax = max(float(v.abs().max()) for k, v in gr.items() if k.endswith("weight"))
+    dead = [k for k in gr if k.endswith("bias") and k not in ("model.0.bias", "model.11.bias")]      # biases in front of InstanceNorm2d: zero gradient
+    if dt == "fp32":
+        assert rel_err(y.cpu(), yr) < F32_TOL and rel_err(xg.grad.cpu(), dxr) < F32_TOL
+        for k, p in net.named_parameters():
+            if k in dead:
+                assert float(p.grad.abs().max()) < 1e-5 * wmax, k
+            else:
+                assert rel_err(p.grad.cpu(), gr[k]) < F32_TOL, k
+    else:
+        ye, dxe, ge = ref(torch.bfloat16 if dt == "bf16" else torch.float16)
+        bound = lambda e: 1.5 * e + 5e-3
+        assert rel_l2(y.cpu(), yr) < bound(rel_l2(ye, yr))
+        assert rel_l2(xg.grad.cpu(), dxr) < bound(rel_l2(dxe, dxr))
+        for k, p in net.named_parameters():
+            if k in dead:           # 16-bit storage of the normalised gradient: rounding noise of the per-image sums, far below the weights' gradients
+                assert float(p.grad.abs().max()) < 2e-2 * wmax, (k, float(p.grad.abs().max()), wmax)
+            else:
+                assert rel_l2(p.grad.cpu(), gr[k]) < bound(rel_l2(ge[k], gr[k])), (k, rel_l2(p.grad.cpu(), gr[k]), rel_l2(ge[k], gr[k]))
+    # frozen pass (the generator step's use of D): input gradient only
+    set_requires_grad(net, False)
+    xf = x.cuda().requires_grad_(True)
+    GANLoss("lsgan", device="cuda")(net(xf), True).backward()
+    assert all(p.grad is None or True for p in net.parameters())
+    err = rel_err if dt == "fp32" else rel_l2
+    assert err(xf.grad.cpu(), dxr) < (F32_TOL if dt == "fp32" else 1.5 * rel_l2(dxe, dxr) + 5e-3)
+
+
 @pytest.mark.parametrize("hw", [(96, 128), (97, 128)])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_nlayerd_full_width_vs_oracle(dt, hw):

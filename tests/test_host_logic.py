@@ -45,6 +45,24 @@ def test_nlayerd_state_dict_matches_reference(tag):
     net.load_state_dict(ref, strict=True)
 
 
+def test_nlayerd_instance_norm_state_dict_matches_reference():
+    """norm_layer = nn.InstanceNorm2d, as the class or as basicModel.get_norm_layer's functools.partial (basicModel.py:24-25): biased
+    convolutions, no normalisation parameters or buffers -- the reference's state_dict loads strictly.  Other norm layers are refused."""
+    import functools
+    g = load_golden("nlayerd_in")
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    ref = sub(g, "sd/")
+    for nl_arg in (torch.nn.InstanceNorm2d, functools.partial(torch.nn.InstanceNorm2d, affine=False, track_running_stats=False)):
+        net = srcgan_amd.NLayerDiscriminator(ic, ndf, nl, norm_layer=nl_arg)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(ref.keys())
+        assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in ref.values()]
+        net.load_state_dict(ref, strict=True)
+    for bad in (torch.nn.GroupNorm, functools.partial(torch.nn.InstanceNorm2d, affine=True), functools.partial(torch.nn.BatchNorm2d, affine=False)):
+        with pytest.raises(NotImplementedError):
+            srcgan_amd.NLayerDiscriminator(ic, ndf, nl, norm_layer=bad)
+
+
 def test_full_size_parameter_counts():
     # SURVEY.md section 8a: 16 619 968 params / 697 tensors ; 2 765 633 / 13
     g = srcgan_amd.RDDBNet(3, 3, 4, nb=23)
@@ -104,7 +122,7 @@ def test_ganloss_modes():
 
 def test_unsupported_norm_layer_is_rejected():
     with pytest.raises(NotImplementedError):
-        srcgan_amd.NLayerDiscriminator(3, 64, 3, norm_layer=torch.nn.InstanceNorm2d)
+        srcgan_amd.NLayerDiscriminator(3, 64, 3, norm_layer=torch.nn.LayerNorm)
 
 
 def test_image_pool_matches_oracle():

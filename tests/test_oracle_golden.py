@@ -86,6 +86,27 @@ def test_nlayer_d(tag):
     assert [(k, tuple(v.shape)) for k, v in mine.items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
 
 
+def test_nlayer_d_instance_norm():
+    """norm_layer = nn.InstanceNorm2d (model/model.py:598-634; fixture: tests/golden/make_golden_inorm.py runs the reference class)."""
+    g = load_golden("nlayerd_in")
+    ic, ndf, nl = [int(v) for v in g["cfg"]]
+    sd = _req(sub(g, "sd/"))
+    assert list(sd.keys()) == oracle.nlayer_d_keys(nl, norm="instance")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.nlayer_d_forward(sd, x, True)
+    loss = oracle.gan_loss(y, True)
+    loss.backward()
+    assert rel_err(y, g["y"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert rel_err(x.grad, g["dx"]) < 1e-4
+    for k, v in sub(g, "grad/").items():
+        assert rel_err(sd[k].grad, v) < 1e-4, k
+    with torch.no_grad():
+        assert rel_err(oracle.nlayer_d_forward(sd, x, False), g["y_eval"]) < TOL
+    mine = oracle.nlayer_d_state(ic, ndf, nl, norm="instance")
+    assert [(k, tuple(v.shape)) for k, v in mine.items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+
+
 def test_losses():
     g = load_golden("losses")
     b = torch.from_numpy(g["b"])
