@@ -346,6 +346,10 @@ typedef struct srcgan_resdeconv_cfg {
     int in_ch, out_ch;     /* in_ch must be 3 (a 1-channel source is replicated by the caller, resdeconv.py:166-167) */
     int B, H, W;
     int dtype;
+    int layers[4];         /* BasicBlocks per stage, resdeconv.py:107,123-137 ([2,2,2,2] = ResNet-18 layout, [3,4,6,3] = ResNet-34);
+                            * all zero = [2,2,2,2].  The up path uses layers[2], layers[1], layers[0]. */
+    int norm;              /* 0 = BN='GN': nn.GroupNorm(32, C) (the reference's default); 1 = BN='IN': nn.InstanceNorm2d(C), which has
+                            * no parameters -- the state_dict then holds the convolution weights only */
 } srcgan_resdeconv_cfg;
 int srcgan_resdeconv_num_params(const srcgan_resdeconv_cfg* c);
 size_t srcgan_resdeconv_ws_bytes(const srcgan_resdeconv_cfg* c);

@@ -173,30 +173,38 @@ def legacy_keys(nb: int, tail) -> List[str]:
 # Colouriser: ResDeconv  (reference src/model/resdeconv.py:56-195, BN='GN', layers=[2,2,2,2])
 # ---------------------------------------------------------------------------
 
+def _rd_norm(sd: State, key: str, t: Tensor) -> Tensor:
+    """the block's normalisation layer: nn.GroupNorm(32, C) (BN='GN', parameters in the state_dict) or nn.InstanceNorm2d(C)
+    (BN='IN': no parameters, resdeconv.py:117-121,150-155)."""
+    if key + ".weight" in sd:
+        return F.group_norm(t, 32, sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+    return F.instance_norm(t, None, None, None, None, True, 0.1, 1e-5)
+
+
 def _rd_block(sd: State, pre: str, x: Tensor, stride: int) -> Tensor:
-    """BasicBlock.forward, resdeconv.py:78-97 (GroupNorm(32), ReLU; 1x1 strided conv + GroupNorm shortcut when present)."""
-    gn = lambda t, n: F.group_norm(t, 32, sd[pre + n + ".weight"], sd[pre + n + ".bias"], 1e-5)
-    out = _st(F.relu(gn(_st(F.conv2d(x, _st(sd[pre + "conv1.weight"]), None, stride, 1)), "bn1")))
-    out = gn(_st(F.conv2d(out, _st(sd[pre + "conv2.weight"]), None, 1, 1)), "bn2")
+    """BasicBlock.forward, resdeconv.py:78-97 (norm, ReLU; 1x1 strided conv + norm shortcut when present)."""
+    out = _st(F.relu(_rd_norm(sd, pre + "bn1", _st(F.conv2d(x, _st(sd[pre + "conv1.weight"]), None, stride, 1)))))
+    out = _rd_norm(sd, pre + "bn2", _st(F.conv2d(out, _st(sd[pre + "conv2.weight"]), None, 1, 1)))
     idn = x
     if pre + "downsample.0.weight" in sd:
-        idn = _st(F.group_norm(_st(F.conv2d(x, _st(sd[pre + "downsample.0.weight"]), None, stride, 0)), 32,
-                               sd[pre + "downsample.1.weight"], sd[pre + "downsample.1.bias"], 1e-5))
+        idn = _st(_rd_norm(sd, pre + "downsample.1", _st(F.conv2d(x, _st(sd[pre + "downsample.0.weight"]), None, stride, 0))))
     return _st(F.relu(out + idn))
 
 
 def resdeconv_forward(sd: State, x: Tensor) -> Tensor:
-    """ResDeconv.forward, resdeconv.py:164-195.  A 1-channel source is replicated to the stem's 3 channels."""
+    """ResDeconv.forward, resdeconv.py:164-195, for any ``layers`` (the block count of a stage is read off the state_dict keys) and
+    BN = 'GN' / 'IN'.  A 1-channel source is replicated to the stem's 3 channels."""
     if x.shape[1] == 1:
         x = torch.cat([x, x, x], dim=1)
-    t = _st(F.relu(F.group_norm(_st(F.conv2d(_st(x), _st(sd["conv1.weight"]), None, 2, 3)), 32, sd["bn1.weight"], sd["bn1.bias"], 1e-5)))
+    nblk = lambda name: 1 + max(int(k.split(".")[1]) for k in sd if k.startswith(name + "."))
+    t = _st(F.relu(_rd_norm(sd, "bn1", _st(F.conv2d(_st(x), _st(sd["conv1.weight"]), None, 2, 3)))))
     for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2), ("layer4", 2)):
-        t = _rd_block(sd, f"{name}.0.", t, stride)
-        t = _rd_block(sd, f"{name}.1.", t, 1)
+        for k in range(nblk(name)):
+            t = _rd_block(sd, f"{name}.{k}.", t, stride if k == 0 else 1)
     for dc, name in (("deconv10", "upRes1"), ("deconv11", "upRes2"), ("deconv12", "upRes3")):
         t = _st(F.conv_transpose2d(t, _st(sd[dc + ".weight"]), None, 2, 0))
-        t = _rd_block(sd, f"{name}.0.", t, 1)
-        t = _rd_block(sd, f"{name}.1.", t, 1)
+        for k in range(nblk(name)):
+            t = _rd_block(sd, f"{name}.{k}.", t, 1)
     t = _st(F.conv_transpose2d(t, _st(sd["deconv13.weight"]), None, 2, 0))
     return _st(F.conv2d(t, _st(sd["pred.weight"]), None, 1, 1))
 

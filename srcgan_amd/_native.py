@@ -91,7 +91,8 @@ class NetOpts(C.Structure):
 
 
 class ResDeconvCfg(C.Structure):
-    _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+    _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int),
+                ("layers", C.c_int * 4), ("norm", C.c_int)]
 
 
 class SrNetCfg(C.Structure):

@@ -34,6 +34,16 @@ template <> __device__ __forceinline__ float from_f<float>(float v) { return v; 
 template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
 template <> __device__ __forceinline__ _Float16 from_f<_Float16>(float v) { return (_Float16)v; }
 
+// (count, mean, M2 = sum of squared deviations) of a sample set A joined with those of B -- Chan, Golub, LeVeque: exact in exact arithmetic,
+// no cancellation; used for BatchNorm / GroupNorm / InstanceNorm statistics (elementwise.hip, groupnorm.hip)
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb <= 0.f) return;
+    const float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+}
+
 // 4 consecutive channels <-> f32 registers (8-byte bf16 / 16-byte f32 accesses)
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {

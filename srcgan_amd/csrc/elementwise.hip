@@ -577,13 +577,6 @@ __global__ __launch_bounds__(256) void col_finalize_k(const float* __restrict__ 
 // M2 = S2 - S1^2 / n.  Partials (n, mean, M2) are combined exactly (Chan et al.: M2 = M2a + M2b + d^2 na nb / (na + nb)) in a
 // fixed order: threads of a block by pixel lane, blocks by index -- deterministic.  partial[blk][c] = mean, partial[nblk + blk][c] = M2;
 // a block's count follows from (blk, npix, nblk).
-__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-    if (nb <= 0.f) return;
-    const float nn = n + nb, d = mb - mean;
-    mean += d * (nb / nn);
-    m2 += m2b + d * d * (n * nb / nn);
-    n = nn;
-}
 template <typename T>
 __global__ __launch_bounds__(256) void col_meanvar_vec_k(const T* __restrict__ a, int aCs, int acoff, long npix, int C, float* __restrict__ partial) {
     constexpr int EPP = DT<T>::EPP;

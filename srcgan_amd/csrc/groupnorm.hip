@@ -49,12 +49,25 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
         s0[i] = 0.f; s1[i] = 0.f;
         if (MODE == 1) { const int g = (c0 + i) / cpg; mu[i] = stats[((size_t)b * G + g) * 2]; rs[i] = stats[((size_t)b * G + g) * 2 + 1]; }
     }
+    // MODE 0: sums around the thread's first sample (s0 = sum (v - sh), s1 = sum (v - sh)^2): the variance of ONE channel of ONE image
+    // (InstanceNorm2d: G == C) whose mean is many standard deviations from zero loses its digits in  E[x^2] - mean^2
+    float sh[EPP], nsmp = 0.f;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) sh[i] = 0.f;
+        if (p0 + pl < p1) {
+            const vecT fv = *(const vecT*)(x + ((size_t)b * hw + p0 + pl) * x_cs + c0);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) sh[i] = to_f(fv[i]);
+        }
+    }
     for (long px = p0 + pl; px < p1; px += PL) {
         const size_t q = (size_t)b * hw + px;
         const vecT xv = *(const vecT*)(x + q * x_cs + c0);
         if (MODE == 0) {
+            nsmp += 1.f;
 #pragma unroll
-            for (int i = 0; i < EPP; ++i) { const float v = to_f(xv[i]); s0[i] += v; s1[i] += v * v; }
+            for (int i = 0; i < EPP; ++i) { const float v = to_f(xv[i]) - sh[i]; s0[i] += v; s1[i] += v * v; }
         } else {
             const vecT gv = *(const vecT*)(dy + q * dy_cs + c0);
             vecT av;
@@ -67,14 +80,25 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
             }
         }
     }
+    __shared__ float cnt[256];
+    if (MODE == 0) {        // thread partial -> (count, mean, M2)
+        const float inv = nsmp > 0.f ? 1.f / nsmp : 0.f;
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) { const float a = s0[i]; s0[i] = sh[i] + a * inv; s1[i] = s1[i] - a * a * inv; }
+        cnt[threadIdx.x] = nsmp;
+    }
 #pragma unroll
     for (int i = 0; i < EPP; ++i) { red[0][threadIdx.x * EPP + i] = s0[i]; red[1][threadIdx.x * EPP + i] = s1[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int q = 0; q < PL; ++q) { t0 += red[0][(q * VG + c / EPP) * EPP + c % EPP]; t1 += red[1][(q * VG + c / EPP) * EPP + c % EPP]; }
+        float t0 = 0.f, t1 = 0.f, tn = 0.f;
+        for (int q = 0; q < PL; ++q) {
+            const int t = q * VG + c / EPP;
+            if (MODE == 0) chan_combine(tn, t0, t1, cnt[t], red[0][t * EPP + c % EPP], red[1][t * EPP + c % EPP]);      // fixed order: deterministic
+            else { t0 += red[0][t * EPP + c % EPP]; t1 += red[1][t * EPP + c % EPP]; }
+        }
         float* o = partial + (((size_t)b * nblk + blockIdx.x) * C + c) * 2;
-        o[0] = t0; o[1] = t1;
+        o[0] = t0; o[1] = t1;           // MODE 0: the block's (mean, M2) over its p1 - p0 pixels
     }
 }
 
@@ -85,9 +109,16 @@ __global__ __launch_bounds__(256) void gn_fold_k(const float* __restrict__ parti
                                                  const float* __restrict__ gamma, float* __restrict__ out, float* __restrict__ chan) {
     __shared__ float cs[2][1024];
     const int b = blockIdx.x;
+    const long per = cdivl(hw, (long)nblk);
     for (int c = threadIdx.x; c < C; c += 256) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int k = 0; k < nblk; ++k) { const float* p = partial + (((size_t)b * nblk + k) * C + c) * 2; t0 += p[0]; t1 += p[1]; }
+        float t0 = 0.f, t1 = 0.f, tn = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            const float* p = partial + (((size_t)b * nblk + k) * C + c) * 2;
+            if (MODE == 0) {            // (mean, M2) of block k's pixel range
+                const long p0 = (long)k * per, p1 = (p0 + per < hw) ? p0 + per : hw;
+                chan_combine(tn, t0, t1, p1 > p0 ? (float)(p1 - p0) : 0.f, p[0], p[1]);
+            } else { t0 += p[0]; t1 += p[1]; }
+        }
         if (MODE == 1) { chan[((size_t)b * C + c) * 2] = t0; chan[((size_t)b * C + c) * 2 + 1] = t1; if (gamma) { t0 *= gamma[c]; t1 *= gamma[c]; } }
         cs[0][c] = t0; cs[1][c] = t1;
     }
@@ -95,10 +126,13 @@ __global__ __launch_bounds__(256) void gn_fold_k(const float* __restrict__ parti
     const int cpg = C / G;
     const float invn = 1.f / ((float)hw * (float)cpg);
     for (int g = threadIdx.x; g < G; g += 256) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int i = 0; i < cpg; ++i) { t0 += cs[0][g * cpg + i]; t1 += cs[1][g * cpg + i]; }
+        float t0 = 0.f, t1 = 0.f, tn = 0.f;
+        for (int i = 0; i < cpg; ++i) {
+            if (MODE == 0) chan_combine(tn, t0, t1, (float)hw, cs[0][g * cpg + i], cs[1][g * cpg + i]);      // channel (mean, M2) over hw pixels each
+            else { t0 += cs[0][g * cpg + i]; t1 += cs[1][g * cpg + i]; }
+        }
         float* o = out + ((size_t)b * G + g) * 2;
-        if (MODE == 0) { const float m = t0 * invn; float v = t1 * invn - m * m; v = v > 0.f ? v : 0.f; o[0] = m; o[1] = rsqrtf(v + eps); }
+        if (MODE == 0) { o[0] = t0; o[1] = rsqrtf(t1 * invn + eps); }
         else { o[0] = t0 * invn; o[1] = t1 * invn; }
     }
 }

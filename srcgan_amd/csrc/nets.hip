@@ -1068,7 +1068,8 @@ struct RdT { int C, cs, H, W, act; size_t off; };       // act: produced by a co
 struct RdOp {
     int type;                 // 0 conv (+bias)(+ReLU), 1 GroupNorm(+res)(+ReLU), 2 ConvTranspose2d k2 s2, 3 PixelShuffle(r)
     int in, out, res, relu;
-    int k, s, pad, w, bias;   // w: parameter index of the weight (GroupNorm: gamma, beta = w + 1); bias: parameter index or -1
+    int k, s, pad, w, bias;   // w: parameter index of the weight (GroupNorm: gamma, beta = w + 1; -1 = no affine part); bias: parameter index or -1
+    int ngrp;                 // GroupNorm: groups (InstanceNorm2d: = channels)
     float slope;              // GroupNorm activation: 0 = ReLU, 0.2 = LeakyReLU (edsr.py:42)
     size_t wf[4], wd[4], stats;
 };
@@ -1082,6 +1083,7 @@ struct RdPlan {
 
 struct RdBuilder {
     RdPlan& P; Bump b; int np = 0; int B;
+    int inorm = 0;            // normalisation layers are InstanceNorm2d (no parameters) instead of GroupNorm(32, C)
     RdBuilder(RdPlan& p, int B_) : P(p), B(B_) {}
     int tensor(int C, int cs, int H, int W, int act = 0) { P.T.push_back(RdT{C, cs, H, W, act, b.take((size_t)B * H * W * cs * P.esz)}); return (int)P.T.size() - 1; }
     int conv(int in, int cout, int k, int s, int pad, bool bias = false, bool relu = false) {
@@ -1095,8 +1097,9 @@ struct RdBuilder {
     int gn(int in, int res, int relu) {
         const RdT ti = P.T[in];
         RdOp o; memset(&o, 0, sizeof(o));
-        o.type = 1; o.in = in; o.out = tensor(ti.C, ti.cs, ti.H, ti.W); o.res = res; o.relu = relu; o.w = np; np += 2; o.bias = -1;
-        o.stats = b.take((size_t)B * 32 * 2 * sizeof(float));
+        o.type = 1; o.in = in; o.out = tensor(ti.C, ti.cs, ti.H, ti.W); o.res = res; o.relu = relu; o.bias = -1;
+        if (inorm) { o.w = -1; o.ngrp = ti.C; } else { o.w = np; np += 2; o.ngrp = 32; }
+        o.stats = b.take((size_t)B * o.ngrp * 2 * sizeof(float));
         P.ops.push_back(o); return o.out;
     }
     int deconv(int in, int cout) {
@@ -1118,11 +1121,11 @@ struct RdBuilder {
         int t = conv(x, planes, 3, stride, 1);
         t = gn(t, -1, 1);
         t = conv(t, planes, 3, 1, 1);
-        const int gn2_param = np; np += 2;                  // bn2's parameters precede the shortcut's in the state_dict
+        const int gn2_param = np; if (!inorm) np += 2;      // bn2's parameters precede the shortcut's in the state_dict
         int idn = x;
         if (ds) { idn = conv(x, planes, 1, stride, 0); idn = gn(idn, -1, 0); }
         const int out = gn(t, idn, 1);
-        P.ops.back().w = gn2_param; np -= 2;
+        if (!inorm) { P.ops.back().w = gn2_param; np -= 2; }
         return out;
     }
     void input(int in_ch, int H, int W) {
@@ -1190,14 +1193,26 @@ static int rd_plan(const srcgan_resdeconv_cfg* c, RdPlan& P) {
     SG_TRY(rd_common(c->dtype, c->B, c->H, c->W, P, "resdeconv"));
     SG_REQUIRE(c->in_ch == 3 && c->out_ch > 0 && c->out_ch <= 8, "resdeconv: the stem takes 3 channels (resdeconv.py:113), tar_ch must be in 1..8");
     SG_REQUIRE(c->H % 16 == 0 && c->W % 16 == 0, "resdeconv: H and W must be multiples of 16 (four stride-2 stages mirrored by four x2 deconvolutions)");
+    int layers[4];
+    const bool dflt = c->layers[0] == 0 && c->layers[1] == 0 && c->layers[2] == 0 && c->layers[3] == 0;
+    for (int l = 0; l < 4; ++l) {
+        layers[l] = dflt ? 2 : c->layers[l];
+        SG_REQUIRE(layers[l] >= 1 && layers[l] <= 64, "resdeconv: layers[%d] = %d (1..64 BasicBlocks per stage)", l, layers[l]);
+    }
+    SG_REQUIRE(c->norm == 0 || c->norm == 1, "resdeconv: norm must be 0 (GroupNorm(32, C)) or 1 (InstanceNorm2d)");
     RdBuilder nb(P, c->B);
+    nb.inorm = c->norm == 1;
     nb.input(c->in_ch, c->H, c->W);
     int t = nb.conv(0, 64, 7, 2, 3);
     t = nb.gn(t, -1, 1);
     const int widths[4] = {64, 128, 256, 512};
-    for (int l = 0; l < 4; ++l) { t = nb.block(t, widths[l], l == 0 ? 1 : 2); t = nb.block(t, widths[l], 1); }
+    for (int l = 0; l < 4; ++l)                 // _make_layer (resdeconv.py:148-163): the first block carries the stride / shortcut
+        for (int k = 0; k < layers[l]; ++k) t = nb.block(t, widths[l], (k == 0 && l > 0) ? 2 : 1);
     const int up_w[3] = {256, 128, 64};
-    for (int l = 0; l < 3; ++l) { t = nb.deconv(t, up_w[l]); t = nb.block(t, up_w[l], 1); t = nb.block(t, up_w[l], 1); }
+    for (int l = 0; l < 3; ++l) {               // upRes1..3 use layers[2], layers[1], layers[0] (resdeconv.py:131-137)
+        t = nb.deconv(t, up_w[l]);
+        for (int k = 0; k < layers[2 - l]; ++k) t = nb.block(t, up_w[l], 1);
+    }
     t = nb.deconv(t, 64);
     nb.conv(t, c->out_ch, 3, 1, 1);
     nb.finish(c->dtype);
@@ -1282,8 +1297,9 @@ static int rd_forward(const RdPlan& P, const float* x_nchw, const float* const* 
             SG_TRY(cv.run(st));
         } else if (o.type == 1) {
             const void* res = o.res >= 0 ? (w8 + P.T[o.res].off) : nullptr;
-            SG_TRY(srcgan_gn_forward(xin.p, ti.cs, res, o.res >= 0 ? P.T[o.res].cs : 0, out.p, to.cs, params[o.w], params[o.w + 1],
-                                     (float*)(w8 + o.stats), B, (long)ti.H * ti.W, ti.C, 32, 1e-5f, o.relu, o.slope, dt, gnscr, st));
+            SG_TRY(srcgan_gn_forward(xin.p, ti.cs, res, o.res >= 0 ? P.T[o.res].cs : 0, out.p, to.cs, o.w >= 0 ? params[o.w] : nullptr,
+                                     o.w >= 0 ? params[o.w + 1] : nullptr, (float*)(w8 + o.stats), B, (long)ti.H * ti.W, ti.C, o.ngrp, 1e-5f, o.relu,
+                                     o.slope, dt, gnscr, st));
         } else if (o.type == 2) {
             for (int q = 0; q < 4; ++q)
                 SG_TRY(Conv(dt, 1, 1, 1).in(xin, B, ti.H, ti.W, ti.C).w(wp + o.wf[q]).out(out, ti.H, ti.W, to.C)
@@ -1390,10 +1406,11 @@ static int rd_backward(const RdPlan& P, const float* dy_nchw, float* dx_nchw, co
                 dres = s8 + P.g[o.res]; dres_cs = P.T[o.res].cs; dres_acc = written[o.res]; written[o.res] = 1;
             }
             SG_REQUIRE(!acc && !ti.act, "%s backward: internal error (GroupNorm input has two consumers or a fused activation)", tag);
-            const int pacc = seen_param[o.w];       // a GroupNorm module applied more than once (edsr.py:41,47,49): gradients add
-            seen_param[o.w] = 1;
-            SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, params[o.w], (const float*)(w8 + o.stats),
-                                      dx.p, ti.cs, dres, dres_cs, dres_acc, G(o.w), G(o.w + 1), pacc, o.slope, B, (long)ti.H * ti.W, ti.C, 32, dt, gnscr, st));
+            const int pacc = o.w >= 0 ? seen_param[o.w] : 0;       // a GroupNorm module applied more than once (edsr.py:41,47,49): gradients add
+            if (o.w >= 0) seen_param[o.w] = 1;
+            SG_TRY(srcgan_gn_backward(dy.p, to.cs, o.relu ? (w8 + to.off) : nullptr, to.cs, xin.p, ti.cs, o.w >= 0 ? params[o.w] : nullptr,
+                                      (const float*)(w8 + o.stats), dx.p, ti.cs, dres, dres_cs, dres_acc, o.w >= 0 ? G(o.w) : nullptr,
+                                      o.w >= 0 ? G(o.w + 1) : nullptr, pacc, o.slope, B, (long)ti.H * ti.W, ti.C, o.ngrp, dt, gnscr, st));
             written[o.in] = 1;
         } else if (o.type == 2) {
             if (G(o.w))     // dW[ci][co][a][b] = sum x[y,x,ci] * dy[2y+a,2x+b,co]: wgrad with roles (dy := x, x := dy), k2 s2

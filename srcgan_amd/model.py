@@ -381,7 +381,7 @@ class _ResDeconvFn(torch.autograd.Function):
     """One native forward / one native backward for the whole colouriser (resdeconv.py:164-195)."""
 
     @staticmethod
-    def forward(ctx, x, out_ch, dtype, *params):
+    def forward(ctx, x, out_ch, dtype, layers, norm, *params):
         N.require_cuda(x, "ResDeconv.forward")
         lib = N.lib()
         if x.dim() != 4 or x.shape[1] != 3:
@@ -390,7 +390,7 @@ class _ResDeconvFn(torch.autograd.Function):
         B, _, H, W = x.shape
         if H % 16 or W % 16:
             raise ValueError(f"ResDeconv needs H and W to be multiples of 16 (four stride-2 stages), got {H}x{W}")
-        cfg = N.ResDeconvCfg(3, out_ch, B, H, W, dtype)
+        cfg = N.ResDeconvCfg(3, out_ch, B, H, W, dtype, (C.c_int * 4)(*layers), norm)
         for p in params:
             N.require_cuda(p, "ResDeconv parameter")
         plist = [p.detach().contiguous() for p in params]
@@ -413,7 +413,7 @@ class _ResDeconvFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dy = dy.contiguous().float()
         dx = torch.empty(cfg.B, 3, cfg.H, cfg.W, dtype=torch.float32, device=dy.device) if need_dx else None
-        arena = _GradArena(params, [ctx.needs_input_grad[3 + i] for i in range(len(params))])
+        arena = _GradArena(params, [ctx.needs_input_grad[5 + i] for i in range(len(params))])
         grads = arena.views
         scratch = N.workspace(lib.srcgan_resdeconv_bwd_scratch_bytes(C.byref(cfg)), dy.device)
         N.check(lib.srcgan_resdeconv_backward(C.byref(cfg), dy.data_ptr(), N.ptr_array(params), ctx.ws.data_ptr(), scratch.data_ptr(),
@@ -421,61 +421,66 @@ class _ResDeconvFn(torch.autograd.Function):
         ctx.ws = None
         if ctx.phase_hook is not None:
             ctx.phase_hook.phase_done(arena, params, cfg, 0, 0, 0)
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
 class _BasicBlockHolder(_HolderOnly):
     """Parameter holder of resdeconv.py:56-76 BasicBlock (attribute order = the reference's state_dict order)."""
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, BN="GN"):
         super().__init__()
+        norm = (lambda c: nn.InstanceNorm2d(c)) if BN == "IN" else (lambda c: nn.GroupNorm(32, c))
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.GroupNorm(32, planes)
+        self.bn1 = norm(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.GroupNorm(32, planes)
+        self.bn2 = norm(planes)
         self.downsample = downsample
         self.stride = stride
 
 
 class ResDeconv(nn.Module):
-    """Colouriser, drop-in for reference ``model.ResDeconv`` (src/model/resdeconv.py:99-195, BN='GN', layers=[2,2,2,2]):
+    """Colouriser, drop-in for reference ``model.ResDeconv`` (src/model/resdeconv.py:99-195):
     ``ResDeconv(src_ch=1, tar_ch=3, block=None, layers=[2, 2, 2, 2], BN='GN')`` -- the reference's positional signature
-    (resdeconv.py:107); the native kernels implement its defaults (BasicBlock, ResNet-18 layout, GroupNorm(32)), anything else
-    is refused.  ``forward(x[B,src_ch,H,W]) -> [B,tar_ch,H,W]`` (H, W multiples of 16).
+    (resdeconv.py:107).  ``block``: BasicBlock, the only block the reference defines.  ``layers``: BasicBlocks per stage, any
+    counts ([2, 2, 2, 2] = ResNet-18 layout, the default; [3, 4, 6, 3] = ResNet-34); the up path uses layers[2], layers[1],
+    layers[0] (resdeconv.py:131-137).  ``BN``: 'GN' (GroupNorm(32, C), the default) or 'IN' (nn.InstanceNorm2d(C): no parameters);
+    'BN' (BatchNorm2d) is refused.  ``forward(x[B,src_ch,H,W]) -> [B,tar_ch,H,W]`` (H, W multiples of 16).
     A 1-channel source is replicated to 3 channels like the reference (resdeconv.py:166-167)."""
 
     def __init__(self, src_ch=1, tar_ch=3, block=None, layers=(2, 2, 2, 2), BN="GN", dtype=None):
         super().__init__()
         if block is not None and getattr(block, "__name__", str(block)) not in ("BasicBlock", "_BasicBlockHolder"):
-            raise NotImplementedError("native ResDeconv implements the reference default block=BasicBlock")
-        if list(layers) != [2, 2, 2, 2]:
-            raise NotImplementedError("native ResDeconv implements the reference default layers=[2, 2, 2, 2]")
-        if BN != "GN":
-            raise NotImplementedError("native ResDeconv implements the reference default BN='GN' (GroupNorm(32, C))")
+            raise NotImplementedError("native ResDeconv implements block=BasicBlock (the only block resdeconv.py defines)")
+        layers = [int(v) for v in layers]
+        if len(layers) != 4 or min(layers) < 1:
+            raise ValueError("ResDeconv: layers must be four positive block counts")
+        if BN not in ("GN", "IN"):
+            raise NotImplementedError("native ResDeconv implements BN='GN' (GroupNorm(32, C), the reference's default) and BN='IN' (InstanceNorm2d)")
         self.src_ch = src_ch
         if isinstance(tar_ch, list):
             tar_ch = sum(tar_ch)
         self.tar_ch = tar_ch
+        self.layers_cfg, self.BN = tuple(layers), BN
         self.inplanes = 64
         # creation order == the reference's (it fixes which random numbers each default initialisation consumes)
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.GroupNorm(32, 64)
+        self.bn1 = nn.InstanceNorm2d(64) if BN == "IN" else nn.GroupNorm(32, 64)
         self.relu = nn.ReLU(inplace=True)
-        self.layer1 = self._make_layer(64, 2, 1)
-        self.layer2 = self._make_layer(128, 2, 2)
-        self.layer3 = self._make_layer(256, 2, 2)
-        self.layer4 = self._make_layer(512, 2, 2)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
         self.deconv10 = nn.ConvTranspose2d(512, 256, 2, 2, 0, bias=False)
         self.inplanes = 256
-        self.upRes1 = self._make_layer(256, 2, 1)
+        self.upRes1 = self._make_layer(256, layers[2], 1)
         self.deconv11 = nn.ConvTranspose2d(256, 128, 2, 2, 0, bias=False)
         self.inplanes = 128
-        self.upRes2 = self._make_layer(128, 2, 1)
+        self.upRes2 = self._make_layer(128, layers[1], 1)
         self.deconv12 = nn.ConvTranspose2d(128, 64, 2, 2, 0, bias=False)
         self.inplanes = 64
-        self.upRes3 = self._make_layer(64, 2, 1)
+        self.upRes3 = self._make_layer(64, layers[0], 1)
         self.deconv13 = nn.ConvTranspose2d(64, 64, 2, 2, 0, bias=False)
         self.pred = nn.Conv2d(64, tar_ch, kernel_size=3, stride=1, padding=1, bias=False)
         _kaiming_like_reference(self)
@@ -483,19 +488,19 @@ class ResDeconv(nn.Module):
 
     def _make_layer(self, planes, blocks, stride):
         downsample = None
-        norm = nn.GroupNorm(32, planes)
+        norm = nn.InstanceNorm2d(planes) if self.BN == "IN" else nn.GroupNorm(32, planes)
         if stride != 1 or self.inplanes != planes:
             downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False), norm)
-        layers = [_BasicBlockHolder(self.inplanes, planes, stride, downsample)]
+        layers = [_BasicBlockHolder(self.inplanes, planes, stride, downsample, BN=self.BN)]
         self.inplanes = planes
         for _ in range(1, blocks):
-            layers.append(_BasicBlockHolder(self.inplanes, planes))
+            layers.append(_BasicBlockHolder(self.inplanes, planes, BN=self.BN))
         return nn.Sequential(*layers)
 
     def forward(self, x):
         if self.src_ch == 1:
             x = torch.cat([x, x, x], dim=1)
-        return _ResDeconvFn.apply(x, self.tar_ch, N.dtype_id(self.compute_dtype), *self.parameters())
+        return _ResDeconvFn.apply(x, self.tar_ch, N.dtype_id(self.compute_dtype), self.layers_cfg, 1 if self.BN == "IN" else 0, *self.parameters())
 
     def extra_repr(self):
         return f"native gfx950, compute_dtype={self.compute_dtype}"

@@ -239,7 +239,8 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int 
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
     scr = torch.empty(lib.srcgan_gn_scratch_floats(B, Cc), dtype=torch.float32, device=x.device)
     N.check(lib.srcgan_gn_forward(x.data_ptr(), Cc, res.data_ptr() if res is not None else None, Cc, y.data_ptr(), Cc,
-                                  gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), B, H * W, Cc, G, eps, int(relu), slope,
+                                  gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, stats.data_ptr(),
+                                  B, H * W, Cc, G, eps, int(relu), slope,
                                   N.dtype_id(x.dtype), scr.data_ptr(), N.stream_ptr(x.device)), "srcgan_gn_forward")
     return y, stats
 
@@ -256,7 +257,8 @@ def group_norm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats
     dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
     scr = torch.empty(lib.srcgan_gn_scratch_floats(B, Cc), dtype=torch.float32, device=x.device)
     N.check(lib.srcgan_gn_backward(dy.data_ptr(), Cc, yact.data_ptr() if yact is not None else None, Cc, x.data_ptr(), Cc,
-                                   gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(), Cc, dres.data_ptr() if want_dres else None, Cc, 0,
+                                   gamma.data_ptr() if gamma is not None else None, stats.data_ptr(), dx.data_ptr(), Cc,
+                                   dres.data_ptr() if want_dres else None, Cc, 0,
                                    dgamma.data_ptr(), dbeta.data_ptr(), 0, slope, B, H * W, Cc, G, N.dtype_id(x.dtype), scr.data_ptr(),
                                    N.stream_ptr(x.device)), "srcgan_gn_backward")
     return dx, dres, dgamma, dbeta

@@ -54,6 +54,29 @@ def main():
         np.savez(os.path.join(OUT, f"{tag}.npz"), **out)
         print(tag, tuple(y.shape), float(loss), len(names), "parameters")
 
+    # ---- the constructor's other options (resdeconv.py:107): BN='IN' (InstanceNorm2d, no parameters) and layers=[3,4,6,3]
+    for tag, (src, tar), shape, seed, layers, BN in (("resdeconv_in", (1, 2), (1, 1, 64, 64), 3, [2, 2, 2, 2], "IN"),
+                                                     ("resdeconv_r34", (1, 3), (1, 1, 32, 48), 3, [3, 4, 6, 3], "GN")):
+        from model.resdeconv import BasicBlock
+        torch.manual_seed(seed)
+        m = ResDeconv(src, tar, BasicBlock, layers, BN)
+        m.train()
+        x = torch.rand(*shape)
+        t = torch.rand(shape[0], tar, shape[2], shape[3])
+        y = m(x)
+        loss = nn.L1Loss()(y, t)
+        loss.backward()
+        names = [k for k, _ in m.named_parameters()]
+        full = [k for k in names if k in FULL or k in ("layer2.3.bn1.weight", "upRes1.5.bn2.bias", "layer1.2.conv1.weight")]
+        out = dict(cfg=np.array([src, tar, seed, *layers, 1 if BN == "IN" else 0]), x=npy(x), t=npy(t), y=npy(y), loss=npy(loss), names=np.array(names))
+        for k, p in m.named_parameters():
+            out["wfp/" + k] = fingerprint(p)
+            out["gfp/" + k] = fingerprint(p.grad)
+            if k in full:
+                out["grad/" + k] = npy(p.grad)
+        np.savez(os.path.join(OUT, f"{tag}.npz"), **out)
+        print(tag, tuple(y.shape), float(loss), len(names), "parameters")
+
 
 if __name__ == "__main__":
     main()

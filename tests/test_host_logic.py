@@ -199,13 +199,17 @@ def test_resdeconv_holder():
     assert tuple(net.deconv10.weight.shape) == (512, 256, 2, 2) and tuple(net.conv1.weight.shape) == (64, 3, 7, 7)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.rand(1, 1, 32, 32))
-    with pytest.raises(NotImplementedError):
-        srcgan_amd.ResDeconv(1, 3, layers=(3, 4, 6, 3))
-    # the reference's positional signature (resdeconv.py:107): src_ch, tar_ch, block, layers, BN -- defaults accepted, the rest refused
+    # the reference's positional signature (resdeconv.py:107): src_ch, tar_ch, block, layers, BN
     srcgan_amd.ResDeconv(1, 3, None, [2, 2, 2, 2], "GN")
-    for bad in ((None, [2, 2, 2, 2], "BN"), (None, [2, 2, 2, 2], "IN"), (torch.nn.Identity, [2, 2, 2, 2], "GN")):
+    r34 = srcgan_amd.ResDeconv(1, 3, None, [3, 4, 6, 3], "GN")              # ResNet-34 layout: 191 parameter tensors
+    assert len(list(r34.parameters())) == 191 and "layer3.5.bn2.bias" in r34.state_dict() and "upRes1.5.conv2.weight" in r34.state_dict()
+    inn = srcgan_amd.ResDeconv(1, 3, None, [2, 2, 2, 2], "IN")              # InstanceNorm2d: convolution weights only
+    assert len(list(inn.parameters())) == 37 and all("bn" not in k and "downsample.1" not in k for k in inn.state_dict())
+    for bad in ((None, [2, 2, 2, 2], "BN"), (torch.nn.Identity, [2, 2, 2, 2], "GN")):
         with pytest.raises(NotImplementedError):
             srcgan_amd.ResDeconv(1, 3, *bad)
+    with pytest.raises(ValueError):
+        srcgan_amd.ResDeconv(1, 3, None, [2, 2, 2], "GN")
     from srcgan_amd import train as T
     assert T.CasParams().CModel == "ResDeconv" and T.MODEL_REGISTRY["ResDeconv"] is srcgan_amd.ResDeconv
 

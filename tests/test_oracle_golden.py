@@ -218,16 +218,23 @@ def _fp(t):
     return np.array([float(t.sum()), float((t * t).sum()), *[float(v) for v in t[:4]]])
 
 
-@pytest.mark.parametrize("tag", ["resdeconv_gray", "resdeconv_rgb"])
+def _resdeconv_from_cfg(g, **kw):
+    """holder built like the fixture's reference instance: cfg = [src, tar, seed] or [src, tar, seed, l0, l1, l2, l3, BN == 'IN']"""
+    import srcgan_amd
+    cfg = [int(v) for v in g["cfg"]]
+    src, tar, seed = cfg[:3]
+    layers, BN = (cfg[3:7], "IN" if cfg[7] else "GN") if len(cfg) > 3 else ([2, 2, 2, 2], "GN")
+    torch.manual_seed(seed)
+    return srcgan_amd.ResDeconv(src, tar, None, layers, BN, **kw)
+
+
+@pytest.mark.parametrize("tag", ["resdeconv_gray", "resdeconv_rgb", "resdeconv_in", "resdeconv_r34"])
 def test_resdeconv(tag):
     """ResDeconv colouriser (reference src/model/resdeconv.py:99-195).  The 60 MB state_dict is not stored: the build's
     parameter holders reproduce the reference's seeded initial weights (fingerprints checked), then the oracle
     restatement must reproduce the reference's output, loss and every parameter gradient's fingerprint."""
-    import srcgan_amd
     g = load_golden(tag)
-    src, tar, seed = [int(v) for v in g["cfg"]]
-    torch.manual_seed(seed)
-    holder = srcgan_amd.ResDeconv(src, tar)
+    holder = _resdeconv_from_cfg(g)          # (resdeconv_in: BN='IN', no normalisation parameters; resdeconv_r34: layers=[3,4,6,3])
     names = [str(k) for k in g["names"]]
     assert [k for k, _ in holder.named_parameters()] == names
     for k, p in holder.named_parameters():
