@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
     // npar == 4 (ConvTranspose2d k2 s2 as four 1x1 convolutions, rddb.py:28-38, in ONE launch): the ctiles channel tiles are
     // (parity, tile within the parity); the four parities of a spatial tile are consecutive blocks of one XCD, so the input
     // tile comes from HBM once and from that L2 three times (four launches read the input four times)
+    // npar == 2 (16-bit, 64 channels): a 128-row tile = both COLUMN parities of an output pixel pair, the channel-tile index is
+    // the ROW parity; a lane group then writes 256 contiguous bytes and a workgroup whole 8-KiB row segments -- the four-parity
+    // form's 128-byte records 256 bytes apart ran at 2.5 TB/s where the same kernel writing contiguously reaches 4.3
     int ct = L % p.ctiles, par = 0;
     if (p.npar) { const int cpp = p.ctiles / p.npar; par = ct / cpp; ct -= par * cpp; }
     int t = L / p.ctiles;
@@ -130,6 +133,14 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         constexpr int R = decltype(rs)::value;
         if (IG_DBG(p, 8) && c > 0) return;            // diagnostic builds: weight traffic of the first chunk only
         if constexpr (!WPK) {
+            if (MT == 4 && NTAP == 1 && p.wsplit) {      // rows 0..63 / 64..127 of the tile: two 64-row packs [chunk][row][64 B], wsplit bytes apart
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int pc = it * 256 + tid, row = pc >> 2;
+                    wreg[R][it] = *(const u32x4*)(wb + (row >= 64 ? p.wsplit : 0) + ((size_t)c * 64 + (row & 63)) * 64 + (pc & 3) * 16);
+                }
+                return;
+            }
             const char* ws = wb + (size_t)c * NTAP * COT * 64;
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
@@ -282,12 +293,14 @@ __global__ __launch_bounds__(256) void conv_igemm_k(const ConvP p) {
         return;
     }
     ConvP pe = p;
-    if (p.npar) { pe.oa = par >> 1; pe.ob = par & 1; }
+    if (p.npar == 2) { pe.oa = par; pe.ob = 0; }
+    else if (p.npar) { pe.oa = par >> 1; pe.ob = par & 1; }
     if (p.buf16) {
         constexpr int RS = COT * 4 + 16;
+        constexpr bool OPS = !(MT == 4 && NTAP == 1);          // the pixel-pair form of the up-sampler has no residual / mask operands
         char* lw = smem + wave * 32 * RS;
 #pragma unroll
-        for (int q = 0; q < PT; ++q) conv_epilogue_lds_row<T, MT, PT>(pe, acc, q, lw, b, ct, oy0 + wave * PT + q, ox0, lane);
+        for (int q = 0; q < PT; ++q) conv_epilogue_lds_row<T, MT, PT, OPS>(pe, acc, q, lw, b, ct, oy0 + wave * PT + q, ox0, lane);
     } else
         conv_epilogue<T, MT, PT>(pe, acc, b, ct, oy0 + wave * PT, ox0, r, h);
 }
@@ -324,6 +337,9 @@ static int launch_igemm(const ConvP& p, int ctiles, hipStream_t st) {
     return 0;
 }
 
+#ifndef SG_UP_PT
+#define SG_UP_PT 1      // rows per wave of the up-sampler's pixel-pair form (2: 128 accumulator registers beside the 128-row epilogue -- spills, 16 % slower)
+#endif
 template <typename T, int MT>
 static int dispatch_shape(const ConvP& p, int kh, int kw, int s, int ctiles, hipStream_t st) {
 #define SG_CASE(KH_, KW_, S_, PT_, WPK_) \
@@ -416,6 +432,14 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
         SG_REQUIRE(d->npar == 4 && d->stride == 1 && d->os == 2 && d->oa == 0 && d->ob == 0 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 &&
                    !d->sign_in && !d->sign_out, "srcgan_conv_igemm: npar == 4 with a 1x1 kernel needs os == 2, oa == ob == 0 and the four packs wpar_stride bytes apart");
         p.npar = 4; p.wpar = d->wpar_stride;
+        // pixel-pair form: 64 channels of 2 bytes, dense interleaved output -> one 128-row tile per ROW parity writes both column parities
+        if (sg_is16(d->dtype) && d->Cout == 64 && d->y_cs == 64 && d->y_coff == 0 && !d->y_plane && d->YW % 2 == 0 && d->YW == 2 * d->OW && p.buf16 &&
+            !d->bias && !d->r1 && !d->r2 && !d->mz && d->Cin % 32 == 0) {
+            p.npar = 2; p.wpar = 2 * d->wpar_stride; p.wsplit = d->wpar_stride;
+            p.Cout = 128; p.ypix *= 2; p.YW = d->YW / 2; p.osx = 1;
+            if (d->dtype == SRCGAN_F16) return launch_igemm<_Float16, 1, 1, 1, 4, SG_UP_PT, false>(p, 2, st);
+            return launch_igemm<__bf16, 1, 1, 1, 4, SG_UP_PT, false>(p, 2, st);
+        }
     } else if (d->npar) {
         SG_REQUIRE(d->npar == 4 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 && !d->x_plane && !d->y_plane &&
                    !d->sign_in && !d->sign_out && !d->bias,

@@ -20,7 +20,10 @@ struct ConvP {
     int buf16;    // vec16, and every epilogue tensor's channel plane is below 2 GiB: the row epilogue's 32-bit buffer offsets (conv_epilogue_lds_row)
     int rev;      // images are walked last to first
     long wpar;    // dgrad_s2k4 (conv_par4.hip) and the four-parity 1x1 form: bytes between the packs of consecutive output parities
-    int npar;     // conv_igemm_k: 4 = the channel-tile index also selects an output parity (oa, ob) = (par >> 1, par & 1) and its weight pack
+    int npar;     // conv_igemm_k: 4 = the channel-tile index also selects an output parity (oa, ob) = (par >> 1, par & 1) and its weight pack;
+                  // 2 = it selects the ROW parity oa only: a 128-row tile holds both column parities of a pixel pair (osx, wsplit)
+    int osx;      // row epilogue: output pixel step along x (0 = os).  The pair form writes [.., 2H, W, 2 x C] with osx = 1, os = 2
+    long wsplit;  // != 0: rows 64..127 of a 128-row weight tile come from a second 64-row pack wsplit bytes behind the first (1x1 kernels)
     unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
@@ -176,12 +179,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, const f32x16 (
 // wait for loads one by one and put `s_waitcnt vmcnt(0)` -- which on gfx9 counts stores -- at the head of every pass (ISA of the
 // 4x4 stride-2 layers), in kernels whose workgroups run 2-8 K chunks between prologue and epilogue.  All operands of the row are
 // requested before the transposition.  Needs per-lane offsets below 2^32: channel planes below 2 GiB (checked at launch).
-template <typename T, int MT, int PT>
+template <typename T, int MT, int PT, bool OPS = true>
 __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
                                                            int oy, int ox0, int lane) {
     constexpr int COT = 32 * MT, EPP = DT<T>::EPP, LPP = COT / EPP, PPP = 64 / LPP, NP = 32 / PPP;
     constexpr int RS = COT * 4 + 16;
     constexpr unsigned OOB = 0xffffffffu, FLAGS = 0x00020000u;
+    const int osx = p.osx ? p.osx : p.os;          // (OPS == false: an instance without residual / mask operands -- no loads, no registers for them)
     static_assert(EPP * sizeof(T) == 16, "16-byte operand accesses");
     typedef __attribute__((ext_vector_type(EPP))) T vecT;
     const int r = lane & 31, h = lane >> 5;
@@ -197,10 +201,10 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         }
     }
     const bool use_r1 = p.r1 && cok && co0 < p.r1cend, use_r2 = p.r2 && cok && co0 < p.r2cend, use_mz = p.mz && cok && co0 >= p.mzc0;
-    const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + p.ob + (long)ox0 * p.os;       // wave-uniform: first pixel of pass 0
+    const long rowpix = ((long)b * p.YH + (long)oy * p.os + p.oa) * p.YW + p.ob + (long)ox0 * osx;        // wave-uniform: first pixel of pass 0
     const unsigned nrec = oy < p.OH ? 0xfffffff0u : 0u;
     const int xrem = p.OW - ox0 - lx;                // pass k is in range for this lane iff k * PPP < xrem
-    const long lstep = (long)lx * p.os;
+    const long lstep = (long)lx * osx;
     const int ctc = ct * COT;
     const long uy = (long)chan_off<T>(p.ycoff + ctc, p.yplane), u1 = (long)chan_off<T>(p.r1coff + ctc, p.r1plane);
     const long u2 = (long)chan_off<T>(p.r2coff + ctc, p.r2plane), um = (long)chan_off<T>(p.mzcoff + ctc, p.mzplane);
@@ -212,14 +216,16 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
     const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r1 + u1 + rowpix * p.r1pix), 0, p.r1 ? nrec : 0u, FLAGS);
     const __amdgpu_buffer_rsrc_t d2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.r2 + u2 + rowpix * p.r2pix), 0, p.r2 ? nrec : 0u, FLAGS);
     const __amdgpu_buffer_rsrc_t dm = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.mz + um + rowpix * p.mzpix), 0, p.mz ? nrec : 0u, FLAGS);
-    const int sy = PPP * p.os * (int)p.ypix, s1 = PPP * p.os * (int)p.r1pix, s2 = PPP * p.os * (int)p.r2pix, sm = PPP * p.os * (int)p.mzpix;
-    u32x4 r1v[NP], r2v[NP], mzv[NP];
+    const int sy = PPP * osx * (int)p.ypix, s1 = PPP * osx * (int)p.r1pix, s2 = PPP * osx * (int)p.r2pix, sm = PPP * osx * (int)p.mzpix;
+    u32x4 r1v[OPS ? NP : 1], r2v[OPS ? NP : 1], mzv[OPS ? NP : 1];
+    if constexpr (OPS) {
 #pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const bool in = pass * PPP < xrem;
-        r1v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d1, in ? l1 : OOB, pass * s1, 0);
-        r2v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d2, in ? l2 : OOB, pass * s2, 0);
-        mzv[pass] = __builtin_amdgcn_raw_buffer_load_b128(dm, in ? lm : OOB, pass * sm, 0);
+        for (int pass = 0; pass < NP; ++pass) {
+            const bool in = pass * PPP < xrem;
+            r1v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d1, in ? l1 : OOB, pass * s1, 0);
+            r2v[pass] = __builtin_amdgcn_raw_buffer_load_b128(d2, in ? l2 : OOB, pass * s2, 0);
+            mzv[pass] = __builtin_amdgcn_raw_buffer_load_b128(dm, in ? lm : OOB, pass * sm, 0);
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -236,19 +242,19 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
             const f32x4 t = *(const f32x4*)(lds_wave + (pass * PPP + lx) * RS + (c0 + i) * 4);
             v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
-        const vecT a1 = __builtin_bit_cast(vecT, r1v[pass]), a2 = __builtin_bit_cast(vecT, r2v[pass]), am = __builtin_bit_cast(vecT, mzv[pass]);
+        const vecT a1 = __builtin_bit_cast(vecT, r1v[OPS ? pass : 0]), a2 = __builtin_bit_cast(vecT, r2v[OPS ? pass : 0]), am = __builtin_bit_cast(vecT, mzv[OPS ? pass : 0]);
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
-        if (p.r1) {                     // wave-uniform conditions: scalar branches, not exec masks (lanes outside their operand hold zeros)
+        if (OPS && p.r1) {                     // wave-uniform conditions: scalar branches, not exec masks (lanes outside their operand hold zeros)
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta1 * to_f(a1[i]); }
-        if (p.r2) {
+        if (OPS && p.r2) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] += p.beta2 * to_f(a2[i]); }
         if (p.act) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope; }
-        if (p.mz) {
+        if (OPS && p.mz) {
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] *= (!use_mz || to_f(am[i]) > 0.f) ? 1.f : p.mslope; }
         vecT o;
@@ -257,10 +263,10 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, pass * PPP < xrem ? ly : OOB, pass * sy, 0);
     }
 }
-template <typename T, int MT, int PT>
+template <typename T, int MT, int PT, bool OPS = true>
 __device__ __forceinline__ void conv_epilogue_lds_row(const ConvP& p, const f32x16 (&acc)[MT][PT], int q, char* lds_wave, int b, int ct,
                                                       int oy, int ox0, int lane) {
-    conv_epilogue_lds_row_impl<T, MT, PT>(p, acc, q, lds_wave, b, ct, oy, ox0, lane);
+    conv_epilogue_lds_row_impl<T, MT, PT, OPS>(p, acc, q, lds_wave, b, ct, oy, ox0, lane);
 }
 
 // Epilogue of the loader-specialised 3x3 kernel: all PT rows of a wave.  Differences from the per-row form above, each
