@@ -104,6 +104,9 @@ typedef struct srcgan_conv_desc {
      * Cout == 32, os == 1, blocked input: the dense-block convs).  u32 per output pixel (b, oy, ox), bit c = output channel c.
      *   sign_out: written by a forward conv with act != 0 (bit = activation output > 0)
      *   sign_in : read instead of mz:  v *= bit ? 1 : mslope
+     * 64 channels (round 3; Cout / 8 = 8 bytes per output pixel, byte c / 8, bit c % 8): sign_out of the 1x1 four-parity form with act
+     * (the up-sampler's last stage, rddb.py:93-97), sign_in of a 3x3 s1 convolution with Cout == 64 and no other epilogue operand
+     * (conv_last's input gradient, rddb.py:98,113).
      * A descriptor that sets either and does not meet the conditions is refused (no silent fallback). */
     void* sign_out; const void* sign_in;
     /* npar == 4: the input gradient of a 4x4 stride-2 pad-1 convolution (model/model.py:612-634) with all four output parities in

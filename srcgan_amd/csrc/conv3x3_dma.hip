@@ -731,7 +731,8 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
     const bool ls_ok = (p.xplane == 0 || p.xcoff % DT<T>::KCE == 0) && (p.Cin % DT<T>::KCE == 0 || p.nchunk == 1) &&
                        p.pad_y == 1 && p.pad_x == 1 && p.Cout <= 1024 && (18.0 * p.W + 34.0) * (double)p.xpix < 2147483647.0;
     if (p.sgn_in || p.sgn_out)
-        SG_REQUIRE(ls_ok && cfg != 'a' && sizeof(T) == 2 && p.Cout == 32, "conv3x3: sign masks are only handled by the loader-specialised bf16 kernel (Cout == 32)");
+        SG_REQUIRE(ls_ok && cfg != 'a' && sizeof(T) == 2 && (p.Cout == 32 || (p.Cout == 64 && !p.sgn_out && !p.r1 && !p.r2 && !p.mz && p.vec16)),
+                   "conv3x3: sign masks are only handled by the loader-specialised 16-bit kernel (Cout == 32, or Cout == 64 read-only without other operands)");
     if (!ls_ok) cfg = 'a';
     if (p.Cout <= 32) {
         if (cfg == 'a') return launch_dma<T, 1, 8, 2, 2>(p, 1, st);
@@ -772,6 +773,7 @@ static int dispatch_dma(const ConvP& p, hipStream_t st) {
     if (cfg == 'a') return launch_dma<T, 2, 8, 2, 2>(p, ctiles, st);
     if constexpr (sizeof(T) == 2) {
         const int em = (p.r1 ? 1 : 0) | (p.r2 ? 2 : 0) | (p.mz ? 4 : 0);
+        if (p.sgn_in) return launch_ls<T, 2, 4, false, 8>(p, ctiles, st);       // conv_last's input gradient: 8 mask bytes per pixel instead of the 64-channel activation
         if (em == 0) return launch_ls<T, 2, 4, false, 0>(p, ctiles, st);
         if (em == 1) return launch_ls<T, 2, 4, false, 1>(p, ctiles, st);
         if (em == 3) return launch_ls<T, 2, 4, false, 3>(p, ctiles, st);

@@ -400,10 +400,17 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     p.mzpix = (long)d->mz_cs * esz; p.mzplane = pl(d->mz_plane);
     p.rev = d->rev_batch;
     p.sgn_out = (unsigned char*)d->sign_out; p.sgn_in = (const unsigned char*)d->sign_in;
-    if (d->sign_out || d->sign_in)
-        SG_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && sg_is16(d->dtype) && d->Cout == 32 && d->os == 1 && d->oa == 0 && d->ob == 0 &&
-                   d->YH == d->OH && d->YW == d->OW && d->x_plane && !(d->sign_in && d->mz) && (!d->sign_out || d->act),
-                   "srcgan_conv_igemm: sign masks need a 3x3 s1 bf16 conv with Cout == 32 on a blocked input, unscaled output (and act for sign_out, no mz beside sign_in)");
+    if (d->sign_out || d->sign_in) {
+        const bool dense32 = d->kh == 3 && d->kw == 3 && d->stride == 1 && sg_is16(d->dtype) && d->Cout == 32 && d->os == 1 && d->oa == 0 && d->ob == 0 &&
+                             d->YH == d->OH && d->YW == d->OW && d->x_plane && !(d->sign_in && d->mz) && (!d->sign_out || d->act);
+        // 64 channels (8 mask bytes per pixel): written by the up-sampler's 1x1 parity form, read by a 3x3 s1 convolution without other operands
+        const bool up_out = d->sign_out && !d->sign_in && d->kh == 1 && d->kw == 1 && d->npar == 4 && sg_is16(d->dtype) && d->Cout == 64 && d->act;
+        const bool in64 = d->sign_in && !d->sign_out && d->kh == 3 && d->kw == 3 && d->stride == 1 && sg_is16(d->dtype) && d->Cout == 64 && d->os == 1 &&
+                          d->YH == d->OH && d->YW == d->OW && !d->mz && !d->r1 && !d->r2;
+        SG_REQUIRE(dense32 || up_out || in64,
+                   "srcgan_conv_igemm: sign masks need a 3x3 s1 16-bit conv with Cout == 32 on a blocked input, unscaled output (act for sign_out, no mz beside sign_in); "
+                   "or Cout == 64: sign_out of the 1x1 four-parity form with act, sign_in of a 3x3 s1 conv without other operands");
+    }
     p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2; p.slope = d->slope; p.mslope = d->mslope;
     p.act = d->act;
     const int kce = 64 / esz;
@@ -430,7 +437,8 @@ extern "C" int srcgan_conv_igemm(const srcgan_conv_desc* d, void* stream) {
     if (d->npar && d->kh == 1 && d->kw == 1) {
         // four output parities of a stride-2 scatter in one launch: parity q = (oa, ob) = (q >> 1, q & 1) uses the pack at wp + q * wpar_stride
         SG_REQUIRE(d->npar == 4 && d->stride == 1 && d->os == 2 && d->oa == 0 && d->ob == 0 && d->wpar_stride > 0 && d->wpar_stride % 16 == 0 &&
-                   !d->sign_in && !d->sign_out, "srcgan_conv_igemm: npar == 4 with a 1x1 kernel needs os == 2, oa == ob == 0 and the four packs wpar_stride bytes apart");
+                   !d->sign_in, "srcgan_conv_igemm: npar == 4 with a 1x1 kernel needs os == 2, oa == ob == 0 and the four packs wpar_stride bytes apart");
+        SG_REQUIRE(!d->sign_out || p.buf16, "srcgan_conv_igemm: sign_out of the 1x1 four-parity form needs 16-byte accessible output channels");
         p.npar = 4; p.wpar = d->wpar_stride;
         // pixel-pair form: 64 channels of 2 bytes, dense interleaved output -> one 128-row tile per ROW parity writes both column parities
         if (sg_is16(d->dtype) && d->Cout == 64 && d->y_cs == 64 && d->y_coff == 0 && !d->y_plane && d->YW % 2 == 0 && d->YW == 2 * d->OW && p.buf16 &&

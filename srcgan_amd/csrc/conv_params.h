@@ -24,7 +24,8 @@ struct ConvP {
                   // 2 = it selects the ROW parity oa only: a 128-row tile holds both column parities of a pixel pair (osx, wsplit)
     int osx;      // row epilogue: output pixel step along x (0 = os).  The pair form writes [.., 2H, W, 2 x C] with osx = 1, os = 2
     long wsplit;  // != 0: rows 64..127 of a 128-row weight tile come from a second 64-row pack wsplit bytes behind the first (1x1 kernels)
-    unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, 4 bytes per output pixel (loader-specialised 3x3 kernel, Cout == 32)
+    unsigned char* sgn_out; const unsigned char* sgn_in;   // LeakyReLU sign masks, Cout / 8 bytes per output pixel: byte c / 8, bit c % 8 (loader-specialised
+                                                           // 3x3 kernel: Cout == 32 either way, Cout == 64 read only; row epilogue of the generic kernel: written)
     int dbg;      // diagnostic builds only: 1 = skip MFMAs, 2 = skip operand DMA after the first chunk, 4 = skip epilogue
     unsigned long long* trace;   // diagnostic: per-barrier timestamps of workgroup 0 (SRCGAN_TRACE=1), else null
 };
@@ -261,6 +262,16 @@ __device__ __forceinline__ void conv_epilogue_lds_row_impl(const ConvP& p, const
 #pragma unroll
         for (int i = 0; i < EPP; ++i) o[i] = from_f<T>(v[i]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, pass * PPP < xrem ? ly : OOB, pass * sy, 0);
+        if constexpr (EPP == 8) {
+            if (p.sgn_out) {        // LeakyReLU sign mask of the stored activation: Cout / 8 bytes per (epilogue) pixel, this lane's 8 channels = one byte
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < EPP; ++i) m |= (v[i] > 0.f ? 1u : 0u) << i;
+                const int mb = p.Cout >> 3;
+                const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(p.sgn_out + rowpix * mb, 0, nrec, FLAGS);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, ds, (cok && pass * PPP < xrem) ? (unsigned)(lstep * mb + (co0 >> 3)) : OOB, pass * PPP * osx * mb, 0);
+            }
+        }
     }
 }
 template <typename T, int MT, int PT, bool OPS = true>
@@ -353,8 +364,9 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
     const long l2 = use_r2 ? lstep * p.r2pix + chan_off<T>(p.r2coff + co0, p.r2plane) : 0;
     const long lm = use_mz ? lstep * p.mzpix + chan_off<T>(p.mzcoff + co0, p.mzplane) : 0;
     constexpr bool SGI = (EM & 8) != 0, SGO = (EM & 16) != 0;
-    static_assert(!(SGI || SGO) || (MT == 1 && EPP == 8), "sign masks: 32 output channels, 8 per lane");
-    const long ls = (long)lx * 4 + (c0 >> 3);          // mask byte of this lane's 8 channels
+    static_assert(!(SGI || SGO) || EPP == 8, "sign masks: 8 channels per lane");
+    constexpr int MB = COT / 8;                      // mask bytes per pixel
+    const long ls = (long)lx * MB + (c0 >> 3);         // mask byte of this lane's 8 channels
     const int xrem = p.OW - ox0 - lx;                // pass k is in range iff k * PPP < xrem
     // 64-row tiles (conv5 / block-input gradient: residual operands, 168-VGPR budget): the residual operands of ALL rows
     // and passes arrive in `pre` (requested in front of the pre-epilogue barrier, conv_lds_rows_request).
@@ -381,7 +393,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
                 const long px = rowpix + pass * pstep;
                 if (use_r1 && ok) r1v[pass % NPF] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
                 if (use_mz && ok) mzv[pass % NPF] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
-                if (SGI && ok) sgv[pass % NPF] = p.sgn_in[px * 4 + ls];
+                if (SGI && ok) sgv[pass % NPF] = p.sgn_in[px * MB + ls];
             }
         }
 #pragma unroll
@@ -404,7 +416,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
             if (!PF) {
                 if (use_r1) r1v[0] = *(const vecT*)((const char*)p.r1 + px * p.r1pix + l1);
                 if (use_mz) mzv[0] = *(const vecT*)((const char*)p.mz + px * p.mzpix + lm);
-                if (SGI) sgv[0] = p.sgn_in[px * 4 + ls];
+                if (SGI) sgv[0] = p.sgn_in[px * MB + ls];
             }
 #pragma unroll
             for (int i = 0; i < EPP; ++i) v[i] = (v[i] + bias[i]) * p.alpha;
@@ -433,7 +445,7 @@ __device__ __forceinline__ void conv_epilogue_lds_rows(const ConvP& p, const f32
                 unsigned m = 0;
 #pragma unroll
                 for (int i = 0; i < EPP; ++i) m |= (v[i] > 0.f ? 1u : 0u) << i;
-                p.sgn_out[px * 4 + ls] = (unsigned char)m;
+                p.sgn_out[px * MB + ls] = (unsigned char)m;
             }
             vecT o;
 #pragma unroll

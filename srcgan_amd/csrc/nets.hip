@@ -149,6 +149,8 @@ struct RddbPlan {
     int dtype, esz, nf, gc, nb, C, nst, ndn, kce, nplane; long plane_bytes;
     int B, H, W;           // input
     size_t bm; long bm_bytes;   // sign masks of a dense buffer's four LeakyReLU slices: offset inside the buffer, bytes per slice (0 = not used)
+    size_t um; long um_bytes;   // sign mask of the last up-sampler stage's output (8 bytes per HR pixel; 0 = not used): conv_last's input gradient
+                                // reads it instead of the 64-channel activation (2.1 GB at the bench size)
     int Ht, Wt;            // trunk resolution
     int HO, WO;            // output resolution
     int in_cs, out_cs;
@@ -234,6 +236,8 @@ static int rddb_plan(const srcgan_rddbnet_cfg* c, RddbPlan& P) {
         }
     }
     P.out = b.take(B * P.HO * P.WO * P.out_cs * e);
+    P.um_bytes = (!no_sign && sg_is16(c->dtype) && c->nf == 64 && P.nst > 0 && c->legacy == 0) ? (long)B * P.HO * P.WO * 8 : 0;
+    P.um = P.um_bytes ? b.take((size_t)P.um_bytes) : 0;
     P.wpk = b.off;
     Bump wb;
     auto pk = [&](int rows, int k, int taps) { return wb.take(srcgan_packed_weight_bytes(rows, k, taps, c->dtype)); };
@@ -315,6 +319,14 @@ extern "C" size_t srcgan_rddbnet_bwd_scratch_bytes(const srcgan_rddbnet_cfg* c) 
 }
 
 extern "C" size_t srcgan_rddbnet_wpack_bytes(const srcgan_rddbnet_cfg* c) { RddbPlan P; if (rddb_plan(c, P)) return 0; return P.total - P.wpk; }
+
+// the four parity packs of up-sampler stage s are equally spaced: the stage runs as ONE launch (conv_igemm.hip, npar), which is also
+// the form that writes the LeakyReLU sign mask of the last stage's output
+static inline bool up_packs_spaced(const RddbPlan& P, int s) {
+    const long wstep = (long)(P.w_up_f[s][1] - P.w_up_f[s][0]);
+    return wstep > 0 && P.w_up_f[s][2] == P.w_up_f[s][0] + 2 * (size_t)wstep && P.w_up_f[s][3] == P.w_up_f[s][0] + 3 * (size_t)wstep;
+}
+static inline bool up_mask_written(const RddbPlan& P) { return P.um_bytes && P.nst > 0 && up_packs_spaced(P, P.nst - 1); }
 
 extern "C" int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const float* x_nchw, const float* const* params,
                                          void* ws, float* y_nchw, const srcgan_net_opts* opt, void* st) {
@@ -426,11 +438,12 @@ extern "C" int srcgan_rddbnet_forward_ex(const srcgan_rddbnet_cfg* c, const floa
     for (int s = 0; s < P.nst; ++s) {
         const int h = H << s, w = W << s;
         const long wstep = (long)(P.w_up_f[s][1] - P.w_up_f[s][0]);
-        if (P.w_up_f[s][2] == P.w_up_f[s][0] + 2 * (size_t)wstep && P.w_up_f[s][3] == P.w_up_f[s][0] + 3 * (size_t)wstep && wstep > 0) {
+        if (up_packs_spaced(P, s)) {
             // all four output parities in one launch (the input is read from HBM once: conv_igemm.hip, npar)
             Conv cv(dt, 1, 1, 1);
             cv.in(T_(P.U[s], nf), B, h, w, nf).w(wp + P.w_up_f[s][0]).out(T_(P.U[s + 1], nf), h, w, nf).scatter(2, 0, 0, 2 * h, 2 * w).lrelu();
             cv.d.npar = 4; cv.d.wpar_stride = wstep;
+            if (P.um_bytes && s == P.nst - 1) cv.sign_out(w8 + P.um);       // LeakyReLU sign of the tensor conv_last reads
             SG_TRY(cv.run(st));
         } else
         for (int q = 0; q < 4; ++q)
@@ -580,7 +593,10 @@ extern "C" int srcgan_rddbnet_backward_ex(const srcgan_rddbnet_cfg* c, const flo
     {
         Conv cv(dt, 3, 3, 1);
         cv.in(dout, B, P.HO, P.WO, P.out_cs).w(wp + P.w_last_d).out(S_(Q.dU[P.nst], nf), P.HO, P.WO, nf).pad(1, 1);
-        if (P.nst > 0) cv.mask(Ul, 0);        // LeakyReLU after the last deconv
+        if (P.nst > 0) {                      // LeakyReLU after the last deconv
+            if (P.um_bytes && up_mask_written(P)) { cv.sign_in(w8 + P.um); cv.d.mslope = 0.2f; }
+            else cv.mask(Ul, 0);
+        }
         SG_TRY(cv.run(st));
     }
     // up-sampler stages, last to first

@@ -380,11 +380,15 @@ def test_conv3x3_sign_masks(ops, cin, hw, dt):
         assert float((d / y_z.float().abs().clamp_min(2.0 ** -14)).max()) <= 2.0 ** -10 and int((d > 0).sum()) <= 1e-4 * d.numel(), int((d > 0).sum())
     else:
         assert torch.equal(y_m, y_z)
-    # refused: 64 output channels, interleaved input
+    # refused: 64 output channels with a mask AND another epilogue operand (the 64-channel reader takes the mask only: 8 bytes per pixel,
+    # test_upsampler_sign_mask_and_its_reader), a 64-channel 3x3 writer, interleaved input
     y64 = torch.zeros(B, H, W, 64, device="cuda", dtype=db.dtype)
+    sign8 = torch.zeros(B, H, W, 8, dtype=torch.uint8, device="cuda")
+    w64 = ops.pack_conv2d_fwd(torch.randn(64, cin, 3, 3).cuda(), dt)
     with pytest.raises(RuntimeError):
-        ops.conv_igemm(db, ops.pack_conv2d_fwd(torch.randn(64, cin, 3, 3).cuda(), dt), y64, kh=3, kw=3, Cin=cin, Cout=64, pad=(1, 1),
-                       x_plane=pl, shape=(B, H, W), sign_in=sign)
+        ops.conv_igemm(db, w64, y64, kh=3, kw=3, Cin=cin, Cout=64, pad=(1, 1), x_plane=pl, shape=(B, H, W), sign_in=sign8, r1=y64, r1_cend=64, beta1=1.0)
+    with pytest.raises(RuntimeError):
+        ops.conv_igemm(db, w64, y64, kh=3, kw=3, Cin=cin, Cout=64, pad=(1, 1), x_plane=pl, shape=(B, H, W), act=True, sign_out=sign8)
     xn = _nhwc(ops, buf, Cc, dt)
     with pytest.raises(RuntimeError):
         ops.conv_igemm(xn, wp, y_m, kh=3, kw=3, Cin=cin, Cout=cout, pad=(1, 1), sign_in=sign)
@@ -598,3 +602,34 @@ def test_deconv_k2s2_all_parities_in_one_launch(ops, dt):
     assert torch.equal(y1, y4)
     ref = F.leaky_relu(F.conv_transpose2d(_q(x, dt), _q(w, dt), None, 2, 0), 0.2)
     assert rel_err(ops.to_nchw(y1).cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_upsampler_sign_mask_and_its_reader(ops, dt):
+    """The up-sampler's last stage writes the LeakyReLU sign of its 64-channel output (8 bytes per HR pixel) and conv_last's input
+    gradient -- a 3x3 s1 convolution to 64 channels -- reads it instead of the activation (rddb.py:93-98,111-113): bits equal
+    (activation > 0), and the masked convolution is bit-identical to the one that reads the activation as its mz operand."""
+    torch.manual_seed(21)
+    B, H, W, C = 2, 9, 37, 64
+    x = torch.rand(B, C, H, W) - 0.5
+    w = torch.randn(C, C, 2, 2) * 0.2
+    xd = _nhwc(ops, x, C, dt)
+    packs = torch.cat([ops.pack_weight(w.cuda(), C, C, 1, 1, 4, C * 4, 0, 0, q, dt).reshape(-1) for q in range(4)])
+    y = torch.zeros(B, 2 * H, 2 * W, C, dtype=xd.dtype, device="cuda")
+    mask = torch.zeros(B, 2 * H, 2 * W, 8, dtype=torch.uint8, device="cuda")
+    ops.conv_igemm(xd, packs, y, kh=1, kw=1, Cout=C, OH=H, OW=W, act=True, os=2, oa=0, ob=0, npar=4, wpar_stride=packs.numel() // 4, sign_out=mask)
+    bits = ((mask.unsqueeze(-1) >> torch.arange(8, device="cuda")) & 1).bool().reshape(B, 2 * H, 2 * W, C)
+    assert torch.equal(bits, y.float() > 0)
+    # the reader: dy (8 padded channels) -> 64 channels, 3x3 s1, times LeakyReLU'(y)
+    dy = _nhwc(ops, torch.rand(B, 3, 2 * H, 2 * W) - 0.5, 8, dt)
+    wl = torch.randn(C, 8, 3, 3) * 0.1
+    wl[:, 3:] = 0
+    wp = ops.pack_conv2d_fwd(wl.cuda(), dt)
+    a = torch.zeros_like(y); b_ = torch.zeros_like(y)
+    ops.conv_igemm(dy, wp, a, kh=3, kw=3, Cin=8, Cout=C, pad=(1, 1), sign_in=mask, mslope=0.2)
+    ops.conv_igemm(dy, wp, b_, kh=3, kw=3, Cin=8, Cout=C, pad=(1, 1), mz=y, mslope=0.2)
+    if dt == "fp16":        # one-ulp differences between kernel instances (v_fma_mixlo_f16, see test_conv3x3_sign_masks)
+        d = (a.float() - b_.float()).abs()
+        assert float((d / b_.float().abs().clamp_min(2.0 ** -14)).max()) <= 2.0 ** -10 and int((d > 0).sum()) <= 1e-4 * d.numel()
+    else:
+        assert torch.equal(a, b_)
