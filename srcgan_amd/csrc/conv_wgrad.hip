@@ -252,15 +252,18 @@ __global__ __launch_bounds__((NCW + (BIASW ? 1 : 0)) * 64) void conv_wgrad_k(con
 // A = the x tile (no halo; transposed fragment reads as in conv_wgrad_k), B = 8 consecutive pixels of a dy channel, read with one
 // aligned ds_read_b128 from nine LDS planes (kx, co) that hold the dy halo tile pre-shifted by kx.  16 MFMAs per tile.
 // The partial sums go to the same slab layout as conv_wgrad_k's ([split][cit][tap][co (32)][ci]), so wgrad_reduce_k serves both.
-template <typename T>
+// KS x KS taps (3 or 4; stride 1, pad 1), NCO output channels: KS * KS * NCO <= 32 columns.  The 4 x 4 form with one channel is the
+// PatchGAN's prediction layer (model/model.py:634).
+template <typename T, int KS, int NCO>
 __global__ __launch_bounds__(256) void wgrad_c3_k(const WgradP p) {
     using D = DT<T>;
     static_assert(sizeof(T) == 2, "16-bit modes");
-    constexpr int TH = 8, TW = 32, PB = 64, DH = TH + 2, DW = TW + 2;
+    static_assert(KS * KS * NCO <= 32 && NCO <= 3, "(tap, channel) pairs are the 32 columns of one MFMA");
+    constexpr int TH = 8, TW = 32, PB = 64, DH = TH + KS - 1, DW = TW + KS - 1, NN = KS * KS * NCO;
     constexpr int NPX = TH * TW * 4, NDP = DH * DW;
     constexpr int XIT = NPX / 256, DIT = (NDP + 255) / 256;
     __shared__ __attribute__((aligned(16))) char lds_x[TH * TW * PB];          // 16 KiB; reused for the cross-wave sum at the end
-    __shared__ __attribute__((aligned(16))) T dyp[3][3][DH][TW];               // [kx][co][halo row][column]: dy[.., column - kx + 1]
+    __shared__ __attribute__((aligned(16))) T dyp[KS][NCO][DH][TW];            // [kx][co][halo row][column]: dy[.., column - kx + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     int cit, split;
     {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void wgrad_c3_k(const WgradP p) {
         for (int it = 0; it < DIT; ++it) {
             const int pc = it * 256 + tid;
             const int lr = pc / DW, lc = pc - lr * DW;
-            const int gy = y0 - 1 + lr, gx = x0 - 1 + lc;
+            const int gy = y0 - (KS - 2) + lr, gx = x0 - (KS - 2) + lc;
             const bool ok = pc < NDP && (unsigned)gy < (unsigned)p.OH && (unsigned)gx < (unsigned)p.OW;
             dmask |= (ok ? 1u : 0u) << it;
             dreg[it] = *(const u32x4*)(dyb + (ok ? (size_t)(gy * p.OW + gx) * p.dyCs * sizeof(T) : 0));
@@ -321,18 +324,18 @@ __global__ __launch_bounds__(256) void wgrad_c3_k(const WgradP p) {
             const int lr = pc / DW, lc = pc - lr * DW;
             const unsigned short c0 = (unsigned short)(v[0] & 0xffffu), c1 = (unsigned short)(v[0] >> 16), c2 = (unsigned short)(v[1] & 0xffffu);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int c = lc + kx - 2;
+            for (int kx = 0; kx < KS; ++kx) {
+                const int c = lc + kx - (KS - 1);
                 if (c < 0 || c >= TW) continue;
                 *(unsigned short*)&dyp[kx][0][lr][c] = c0;
-                *(unsigned short*)&dyp[kx][1][lr][c] = c1;
-                *(unsigned short*)&dyp[kx][2][lr][c] = c2;
+                if (NCO > 1) *(unsigned short*)&dyp[kx][NCO > 1 ? 1 : 0][lr][c] = c1;
+                if (NCO > 2) *(unsigned short*)&dyp[kx][NCO > 2 ? 2 : 0][lr][c] = c2;
             }
         }
     };
     const int gq = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
     const int choff = ((gq & 1) * 16 + 4 * pp) * 2;
-    const int n = r < 27 ? r : 26, tap = n / 3, co = n - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+    const int n = r < NN ? r : NN - 1, tap = n / NCO, co = n - NCO * tap, ky = tap / KS, kx = tap - KS * ky;
     if (t_begin < t_end) issue(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
         commit();
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void wgrad_c3_k(const WgradP p) {
             const int py = 2 * wave + (k >> 1), xh = (k & 1) * 16;
             const char* base = lds_x + (py * TW + xh + 8 * h + qq) * PB + choff;
             const bf16x8 a = tr_frag(base, base + 4 * PB);
-            const bf16x8 bv = *(const bf16x8*)&dyp[kx][co][py - ky + 2][xh + 8 * h];
+            const bf16x8 bv = *(const bf16x8*)&dyp[kx][co][py - ky + KS - 1][xh + 8 * h];
             acc = sg_mfma16<T>(a, bv, acc);
         }
         __syncthreads();
@@ -353,11 +356,11 @@ __global__ __launch_bounds__(256) void wgrad_c3_k(const WgradP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[(wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * 32 + r] = acc[i];
     __syncthreads();
-    float* sp = p.slab + ((size_t)split * p.citiles + cit) * 10 * 1024;
-    for (int e = tid; e < 27 * 32; e += 256) {
+    float* sp = p.slab + ((size_t)split * p.citiles + cit) * (KS * KS + 1) * 1024;
+    for (int e = tid; e < NN * 32; e += 256) {
         const int nn = e >> 5, ci = e & 31;
         const float v = (red[(0 * 32 + ci) * 32 + nn] + red[(1 * 32 + ci) * 32 + nn]) + (red[(2 * 32 + ci) * 32 + nn] + red[(3 * 32 + ci) * 32 + nn]);
-        sp[(nn / 3) * 1024 + (nn % 3) * 32 + ci] = v;
+        sp[(nn / NCO) * 1024 + (nn % NCO) * 32 + ci] = v;
     }
 }
 
@@ -507,17 +510,26 @@ extern "C" int srcgan_conv_wgrad(const srcgan_wgrad_desc* d, void* stream) {
     p.nsplit = d->nsplit > ntiles ? (int)ntiles : d->nsplit;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (sg_is16(d->dtype) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Cout <= 3 && !d->bias_grad &&
-        d->OH == d->H && d->OW == d->W && d->Cin % 32 == 0) {
-        // at most three output channels (conv_last): the (tap, channel) pairs as the N dimension of one product (wgrad_c3_k)
-        p.tiles_x = cdiv(p.OW, 32); p.tiles_y = cdiv(p.OH, 8); p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const bool c3 = d->kh == 3 && d->kw == 3 && d->Cout <= 3 && d->OH == d->H && d->OW == d->W;
+    const bool c1 = d->kh == 4 && d->kw == 4 && d->Cout == 1 && d->OH == d->H - 1 && d->OW == d->W - 1;
+    if (sg_is16(d->dtype) && (c3 || c1) && d->stride == 1 && d->pad_y == 1 && d->pad_x == 1 && !d->bias_grad && d->Cin % 32 == 0) {
+        // at most three output channels (conv_last; the PatchGAN's 4x4 prediction layer): the (tap, channel) pairs as the N dimension of
+        // one product (wgrad_c3_k).  Tiles are taken over the INPUT pixels
+        p.tiles_x = cdiv(p.W, 32); p.tiles_y = cdiv(p.H, 8); p.ntiles = p.B * p.tiles_x * p.tiles_y;
+        p.nsplit = d->nsplit;
         if (p.nsplit > p.ntiles) p.nsplit = p.ntiles;
         const dim3 grid((unsigned)(p.citiles * ((p.nsplit + 7) / 8) * 8), 1, 1);
         const double px = (double)p.B * p.OH * p.OW;
-        const int tok = sg_prof_start(d->dtype == SRCGAN_F16 ? "conv_wgrad<f16,3x3,s1,c3>" : "conv_wgrad<bf16,3x3,s1,c3>", 2.0 * px * 9 * d->Cin * d->Cout,
+        const int tok = sg_prof_start(d->dtype == SRCGAN_F16 ? (c3 ? "conv_wgrad<f16,3x3,s1,c3>" : "conv_wgrad<f16,4x4,s1,c1>") : (c3 ? "conv_wgrad<bf16,3x3,s1,c3>" : "conv_wgrad<bf16,4x4,s1,c1>"),
+                                      2.0 * px * d->kh * d->kw * d->Cin * d->Cout,
                                       ((double)p.B * p.H * p.W * d->Cin + px * d->Cout) * 2, st);
-        if (d->dtype == SRCGAN_F16) hipLaunchKernelGGL(wgrad_c3_k<_Float16>, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(wgrad_c3_k<__bf16>, grid, dim3(256), 0, st, p);
+        if (c3) {
+            if (d->dtype == SRCGAN_F16) hipLaunchKernelGGL((wgrad_c3_k<_Float16, 3, 3>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((wgrad_c3_k<__bf16, 3, 3>), grid, dim3(256), 0, st, p);
+        } else {
+            if (d->dtype == SRCGAN_F16) hipLaunchKernelGGL((wgrad_c3_k<_Float16, 4, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((wgrad_c3_k<__bf16, 4, 1>), grid, dim3(256), 0, st, p);
+        }
         sg_prof_stop(tok, st);
         SG_LAUNCH_CHECK();
         rc = 0;

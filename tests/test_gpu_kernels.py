@@ -636,19 +636,19 @@ def test_upsampler_sign_mask_and_its_reader(ops, dt):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("cout,hw", [(3, (19, 45)), (1, (8, 32)), (3, (64, 96))])
-def test_wgrad_of_a_convolution_with_at_most_three_output_channels(ops, dt, cout, hw):
-    """conv_last (64 -> 3, 3x3 s1 p1, no bias; rddb.py:98,113): its weight gradient takes the (tap, channel)-as-N kernel in 16-bit
-    modes (wgrad_c3_k).  Against autograd of F.conv2d on the quantised operands, ragged and whole tiles, 1 and 3 channels."""
+@pytest.mark.parametrize("k,cout,cin,hw", [(3, 3, 64, (19, 45)), (3, 1, 64, (8, 32)), (3, 3, 64, (64, 96)), (4, 1, 128, (15, 33)), (4, 1, 64, (32, 64)), (4, 1, 512, (9, 12))])
+def test_wgrad_of_a_convolution_with_at_most_three_output_channels(ops, dt, k, cout, cin, hw):
+    """conv_last (64 -> 3, 3x3 s1 p1, no bias; rddb.py:98,113) and the PatchGAN's prediction layer (512 -> 1, 4x4 s1 p1;
+    model/model.py:634): their weight gradients take the (tap, channel)-as-N kernel in 16-bit modes (wgrad_c3_k).  Against autograd
+    of F.conv2d on the quantised operands, ragged and whole tiles."""
     torch.manual_seed(31)
     H, W = hw
-    cin = 64
     x = torch.rand(2, cin, H, W) - 0.5
-    w = (torch.randn(cout, cin, 3, 3) * 0.1).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k) * 0.1).requires_grad_(True)
     xq = _q(x, dt)
     y = F.conv2d(xq, w, None, 1, 1)
     dy = _q(torch.rand_like(y) - 0.5, dt)
     y.backward(dy)
-    gw = torch.full((cout, cin, 3, 3), 7.0, device="cuda")
-    ops.conv_wgrad(_nhwc(ops, dy, 8, dt), _nhwc(ops, x, cin, dt), gw, kh=3, kw=3, stride=1, Cout=cout, Cin=cin, pad=(1, 1), layout=(cin * 9, 9, 3, 1, 0))
+    gw = torch.full((cout, cin, k, k), 7.0, device="cuda")
+    ops.conv_wgrad(_nhwc(ops, dy, 8, dt), _nhwc(ops, x, cin, dt), gw, kh=k, kw=k, stride=1, Cout=cout, Cin=cin, pad=(1, 1), layout=(cin * k * k, k * k, k, 1, 0))
     assert rel_err(gw.cpu(), w.grad) < TOL[dt]
